@@ -1,0 +1,87 @@
+"""ctypes binding of libgoalnet_hip.so (C ABI: include/goalnet_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing or a call
+fails, an exception is raised (task rule ③: "the product path must fail loudly when the HIP extension
+is missing").
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgoalnet_hip.so")
+ABI_VERSION = 1
+STAT_PARTS = 1024
+
+P = c_void_p  # device pointers and the stream travel as void*
+
+# name -> (restype, [argtypes])   — one row per entry point declared in include/goalnet_hip.h
+PROTOTYPES = {
+    "goalnet_abi_version": (c_int, []),
+    "goalnet_last_error": (c_char_p, []),
+    "goalnet_fill_uniform": (c_int, [P, c_int64, c_uint64, c_uint32, c_float, c_float, P]),
+    "goalnet_dropout_mask": (c_int, [P, c_int64, c_uint64, c_uint32, c_float, P]),
+    "goalnet_transpose_inner": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
+    "goalnet_conv3x3_weight_flip": (c_int, [P, P, c_int, c_int, P]),
+    "goalnet_conv1_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "goalnet_conv1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "goalnet_conv1_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "goalnet_pool_bnstats_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bn_finalize": (c_int, [P, P, P, P, P, c_float, c_float, c_int64, c_int, P, P, P, P, P]),
+    "goalnet_bn_bwd_reduce": (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    "goalnet_bn_bwd_finalize": (c_int, [P, P, P, P, c_int64, c_int, P, P, P, P]),
+    "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
+    "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_linear_fwd_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "goalnet_linear_fwd": (c_int, [P, c_int64, P, P, c_int, P, P, c_int, P, c_int64, P, c_int64, P, c_int64,
+                                   c_int, c_int64, c_int, P, c_size_t, P]),
+    "goalnet_linear_bwd_dx": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
+    "goalnet_linear_bwd_dw": (c_int, [P, c_int64, P, c_int64, P, P, c_int, P, c_int, c_int64, c_int, P]),
+    "goalnet_colsum": (c_int, [P, c_int64, c_int, c_int, P, P]),
+    "goalnet_mul": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P]),
+    "goalnet_conv1d_fwd": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv1d_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_relu_bwd": (c_int, [P, P, P, c_int64, P]),
+    "goalnet_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, P]),
+    "goalnet_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, P]),
+    "goalnet_mse_bcast": (c_int, [P, P, c_int, P, P, P]),
+    "goalnet_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, P]),
+}
+
+_lib = None
+
+
+class GoalnetError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgoalnet_hip.so (built by __graft_entry__.build()). Raises if absent — no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GoalnetError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU / eager fallback for the AVM hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.goalnet_abi_version()
+    if v != ABI_VERSION:
+        raise GoalnetError(f"libgoalnet_hip.so ABI {v} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().goalnet_last_error()
+        raise GoalnetError(f"{what}: rc={rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,597 @@
+"""`AVM` — the drop-in for the reference's hot path, running on one MI355X.
+
+Mirrors `/root/reference/utils.py:229-272` (class AVM) and its callers' contract:
+
+    model = AVM(audio_included)                       # main.py:64, 325; baseline.py:63
+    optim.Adam(model.parameters(), lr=1e-3)           # main.py:70 — BEFORE the first forward (Lazy semantics)
+    out = model(audio_input, visual_input)            # audio first; (N,30,B) / list of None, (N,3,H,W) -> (N,1)
+    nn.MSELoss()(out, labels).backward(); optimizer.step()      # main.py:187-193
+    torch.save(model.state_dict(), f) / model.load_state_dict(torch.load(f))   # main.py:66, 263, 282
+
+Same sub-module names (`visbl`, `audbl`, `fusion`) and therefore the same `state_dict` keys, shapes and
+torch-native layouts as the reference. The model is always in train mode, as the reference's is (it never
+calls `.eval()`): BatchNorm uses batch statistics and updates its running buffers on every forward, also
+under `torch.no_grad()`; dropout is live.
+
+All arithmetic runs in libgoalnet_hip.so (hand-written gfx950 kernels) — there is no CPU or eager-PyTorch
+fallback. Parameters live in ONE flat fp32 arena in device layouts (conv weights OHWI, linear5 columns in
+NHWC-flatten order); each `nn.Parameter` is a strided view of it with the reference's logical shape, so
+stock `torch.optim.Adam` works on them, gradients are written straight into a parallel gradient arena,
+and the fused Adam / the DDP all-reduce are single passes over flat memory.
+
+Besides the drop-in surface there is a device-resident fast path, `train_step()`, that runs forward,
+the broadcast MSE, backward, (optional) gradient all-reduce and the fused Adam without leaving the GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.parameter import UninitializedParameter
+
+from . import ops
+from ._lib import STAT_PARTS, GoalnetError
+from .synth import BASE_SEED, DROP_P, TID_DROP
+
+F32 = torch.float32
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+_ALIGN = 64  # arena slots are multiples of 64 floats (256 B)
+
+
+class _Holder(nn.Module):
+    """A sub-module that only owns parameters/buffers (keeps the reference's state_dict key prefixes)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise GoalnetError("sub-modules of the MI355X AVM are parameter holders; call the AVM itself")
+
+
+def _mk_layer(bias=True, bn_channels=0):
+    h = _Holder()
+    h.weight = UninitializedParameter()
+    if bias:
+        h.bias = UninitializedParameter()
+    if bn_channels:
+        h.register_buffer("running_mean", None)
+        h.register_buffer("running_var", None)
+        h.register_buffer("num_batches_tracked", None)
+    return h
+
+
+class _Spec:
+    __slots__ = ("name", "kind", "shape", "numel", "offset", "fan_in")
+
+    def __init__(self, name, kind, shape, fan_in):
+        self.name, self.kind, self.shape, self.fan_in = name, kind, tuple(shape), fan_in
+        self.numel = int(math.prod(shape))
+        self.offset = 0
+
+
+class AVM(nn.Module):
+    def __init__(self, audio_included, device=None, seed: int = BASE_SEED):
+        super().__init__()
+        self.audio_included = audio_included                      # utils.py:235
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self._device = torch.device(device) if device is not None else None
+
+        self.visbl = _Holder()                                     # utils.py:237
+        self.visbl.conv1 = _mk_layer()
+        self.visbl.bnorm1 = _mk_layer(bn_channels=64)
+        self.visbl.conv2 = _mk_layer()
+        self.visbl.bnorm2 = _mk_layer(bn_channels=256)
+        self.visbl.conv3 = _mk_layer()
+        self.visbl.bnorm3 = _mk_layer(bn_channels=512)
+        self.visbl.linear5 = _mk_layer()
+        if audio_included:                                         # utils.py:239-240
+            self.audbl = _Holder()
+            self.audbl.conv1 = _mk_layer()
+            self.audbl.conv2 = _mk_layer()
+            self.audbl.linear3 = _mk_layer()
+        self.fusion = nn.ModuleDict({k: _mk_layer() for k in ("0", "3", "6", "9", "12")})   # utils.py:242-256
+
+        # dropout (utils.py:170, 245-254): "device" = counter-based masks (synth.make_drop_masks formula),
+        # "off" = p := 0, "given" = masks supplied through set_dropout_masks() (parity tests)
+        self.dropout_mode = "device"
+        self.dropout_seed = seed
+        self._drop_step = 0
+        self._given_masks: Optional[List[torch.Tensor]] = None
+
+        self._specs: List[_Spec] = []
+        self._arena = self._garena = self._adam_m = self._adam_v = None
+        self._hw3 = self._l2 = None
+        self._adam_t = 0
+        self._materialized = False
+        self.grad_sync = None          # optional callable(model) run between backward and Adam (ddp.py)
+        self.last_ctx = None
+
+    # ------------------------------------------------------------------------------------------
+    # parameter arena
+    # ------------------------------------------------------------------------------------------
+    def _param_specs(self, hw3: int, l2: int) -> List[_Spec]:
+        """Arena order = gradient-readiness order in backward: [fusion, audbl, linear5.bias | linear5.weight |
+        rest of visbl], so each DDP bucket is one contiguous slice (ddp.py)."""
+        f0_in = 640 if self.audio_included else 512
+        S = []
+
+        def lin(name, out, inn, kind="plain"):
+            S.append(_Spec(name + ".weight", kind, (out, inn), inn))
+            S.append(_Spec(name + ".bias", "plain", (out,), inn))
+
+        lin("fusion.12", 1, 128); lin("fusion.9", 128, 256); lin("fusion.6", 256, 512)
+        lin("fusion.3", 512, 512); lin("fusion.0", 512, f0_in)
+        if self.audio_included:
+            lin("audbl.linear3", 128, 128 * l2)
+            S.append(_Spec("audbl.conv2.weight", "plain", (128, 64, 3), 192)); S.append(_Spec("audbl.conv2.bias", "plain", (128,), 192))
+            S.append(_Spec("audbl.conv1.weight", "plain", (64, 30, 3), 90)); S.append(_Spec("audbl.conv1.bias", "plain", (64,), 90))
+        S.append(_Spec("visbl.linear5.bias", "plain", (512,), 512 * hw3))
+        S.append(_Spec("visbl.linear5.weight", "lin5", (512, 512, hw3), 512 * hw3))      # logical (512, C, HW)
+        for i, (co, ci) in ((3, (512, 256)), (2, (256, 64)), (1, (64, 3))):
+            S.append(_Spec(f"visbl.bnorm{i}.weight", "bn_w", (co,), 0)); S.append(_Spec(f"visbl.bnorm{i}.bias", "bn_b", (co,), 0))
+            S.append(_Spec(f"visbl.conv{i}.weight", "ohwi", (co, ci, 3, 3), ci * 9)); S.append(_Spec(f"visbl.conv{i}.bias", "plain", (co,), ci * 9))
+        off = 0
+        for s in S:
+            s.offset = off
+            off += (s.numel + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._arena_numel = off
+        return S
+
+    def _view(self, arena, s: _Spec):
+        flat = arena[s.offset:s.offset + s.numel]
+        if s.kind == "ohwi":
+            o, i = s.shape[0], s.shape[1]
+            return flat.view(o, 3, 3, i).permute(0, 3, 1, 2)          # logical OIHW over physical OHWI
+        if s.kind == "lin5":
+            o, c, hw = s.shape
+            return flat.view(o, hw, c).permute(0, 2, 1)               # logical (512, C, HW) over physical (512, HW, C)
+        return flat.view(s.shape)
+
+    def _module_of(self, name):
+        mod = self
+        parts = name.split(".")
+        for p in parts[:-1]:
+            mod = mod[p] if isinstance(mod, nn.ModuleDict) else getattr(mod, p)
+        return mod, parts[-1]
+
+    def _require_device(self):
+        if self._device is None or self._device.type != "cuda":
+            raise GoalnetError("the MI355X AVM needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        ops.lib()
+
+    def _materialize(self, hw3: int, l2: int, init: bool = True):
+        """Fix the Lazy shapes (first forward or load_state_dict) and build the arena. Parameters are
+        materialised IN PLACE so an optimizer created earlier keeps valid references (main.py:70)."""
+        if self._materialized:
+            if hw3 != self._hw3 or (self.audio_included and l2 != self._l2):
+                raise RuntimeError(f"input size changed after materialisation: linear5 expects {512 * self._hw3} features "
+                                   f"(got {512 * hw3}), audbl.linear3 {128 * (self._l2 or 0)} (got {128 * l2})")
+            return
+        self._require_device()
+        self._hw3, self._l2 = hw3, l2
+        self._specs = self._param_specs(hw3, l2)
+        dev = self._device
+        self._arena = torch.zeros(self._arena_numel, dtype=F32, device=dev)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if init else 0
+        for k, s in enumerate(self._specs):
+            mod, leaf = self._module_of(s.name)
+            prm = getattr(mod, leaf)
+            view = self._view(self._arena, s)
+            if init:
+                flat = self._arena[s.offset:s.offset + s.numel]
+                if s.kind == "bn_w":
+                    flat.fill_(1.0)
+                elif s.kind != "bn_b":
+                    bound = 1.0 / math.sqrt(s.fan_in)                 # torch default init, SURVEY.md §8(a) row 1
+                    ops.fill_uniform(flat, seed, k, -bound, bound)
+            prm.data = view
+            if isinstance(prm, UninitializedParameter):
+                prm.__class__ = prm.cls_to_become                     # what UninitializedParameter.materialize does
+        for i, c in ((1, 64), (2, 256), (3, 512)):
+            bn = getattr(self.visbl, f"bnorm{i}")
+            bn.running_mean = torch.zeros(c, dtype=F32, device=dev)
+            bn.running_var = torch.ones(c, dtype=F32, device=dev)
+            bn.num_batches_tracked = torch.zeros((), dtype=torch.int64)   # host counter (no launch per forward)
+        self._materialized = True
+
+    def spec(self, name) -> _Spec:
+        for s in self._specs:
+            if s.name == name:
+                return s
+        raise KeyError(name)
+
+    def _pflat(self, name):
+        s = self.spec(name)
+        return self._arena[s.offset:s.offset + s.numel]
+
+    def _gflat(self, name):
+        s = self.spec(name)
+        return self._garena[s.offset:s.offset + s.numel]
+
+    def _ensure_garena(self):
+        if self._garena is None:
+            self._garena = torch.zeros(self._arena_numel, dtype=F32, device=self._device)
+
+    # ------------------------------------------------------------------------------------------
+    # state_dict interchange in the reference's torch-native layouts (main.py:66, 263, 282, 326)
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        if not self._materialized:
+            raise RuntimeError("state_dict() before the first forward / load_state_dict(): parameters are uninitialised")
+        out = {} if destination is None else destination
+        order = self._reference_key_order()
+        for name in order:
+            if name.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                mod, leaf = self._module_of(name)
+                out[prefix + name] = getattr(mod, leaf).detach().cpu().clone()
+                continue
+            s = self.spec(name)
+            flat = self._arena[s.offset:s.offset + s.numel]
+            if s.kind == "ohwi":
+                o, i = s.shape[0], s.shape[1]
+                t = torch.empty(s.numel, dtype=F32, device=self._device)
+                ops.transpose_inner(flat, t, o, 9, i)                  # [O][9][I] -> [O][I][9]
+                t = t.view(o, i, 3, 3)
+            elif s.kind == "lin5":
+                o, c, hw = s.shape
+                t = torch.empty(s.numel, dtype=F32, device=self._device)
+                ops.transpose_inner(flat, t, o, hw, c)                 # [512][HW][C] -> [512][C][HW]
+                t = t.view(o, c * hw)
+            else:
+                t = flat.view(s.shape).clone()
+            out[prefix + name] = t.cpu()
+        return out
+
+    def _reference_key_order(self):
+        from .synth import PARAM_ORDER
+        keys = []
+        for name in PARAM_ORDER:
+            if name.startswith("audbl.") and not self.audio_included:
+                continue
+            keys.append(name)
+            if ".bnorm" in name and name.endswith(".bias"):
+                base = name.rsplit(".", 1)[0]
+                keys += [base + ".running_mean", base + ".running_var", base + ".num_batches_tracked"]
+        return keys
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        w5 = state_dict["visbl.linear5.weight"]
+        if w5.dim() != 2 or w5.shape[0] != 512 or w5.shape[1] % 512:
+            raise RuntimeError(f"visbl.linear5.weight has shape {tuple(w5.shape)}, expected (512, 512*H3*W3)")
+        hw3 = w5.shape[1] // 512
+        l2 = state_dict["audbl.linear3.weight"].shape[1] // 128 if self.audio_included else 0
+        self._materialize(hw3, l2, init=False)
+        expected = set(self._reference_key_order())
+        missing = sorted(expected - set(state_dict.keys()))
+        unexpected = sorted(set(state_dict.keys()) - expected)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing keys {missing}, unexpected keys {unexpected}")
+        with torch.no_grad():
+            for name in expected & set(state_dict.keys()):
+                src = state_dict[name]
+                if name.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                    mod, leaf = self._module_of(name)
+                    getattr(mod, leaf).copy_(src)
+                    continue
+                s = self.spec(name)
+                logical = (s.shape[0], s.shape[1] * s.shape[2]) if s.kind == "lin5" else s.shape
+                if tuple(src.shape) != tuple(logical):
+                    raise RuntimeError(f"size mismatch for {name}: {tuple(src.shape)} vs {tuple(logical)}")
+                flat = self._arena[s.offset:s.offset + s.numel]
+                t = src.detach().to(device=self._device, dtype=F32).contiguous().view(-1)
+                if s.kind == "ohwi":
+                    ops.transpose_inner(t, flat, s.shape[0], s.shape[1], 9)      # [O][I][9] -> [O][9][I]
+                elif s.kind == "lin5":
+                    ops.transpose_inner(t, flat, s.shape[0], s.shape[1], s.shape[2])  # [512][C][HW] -> [512][HW][C]
+                else:
+                    flat.copy_(t)
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ------------------------------------------------------------------------------------------
+    # dropout masks
+    # ------------------------------------------------------------------------------------------
+    def set_dropout_masks(self, masks: Optional[List[torch.Tensor]]):
+        """Parity mode: five (N,width) multiplier tensors [visbl.drop5, fusion.2, .5, .8, .11] used by the next forward."""
+        self.dropout_mode = "given" if masks is not None else "off"
+        self._given_masks = None if masks is None else [m.to(self._device, F32).contiguous() for m in masks]
+
+    def _masks(self, n: int):
+        if self.dropout_mode == "off":
+            return [None] * 5
+        if self.dropout_mode == "given":
+            for m, wdt in zip(self._given_masks, (512, 512, 512, 256, 128)):
+                if tuple(m.shape) != (n, wdt):
+                    raise RuntimeError(f"dropout mask shape {tuple(m.shape)} != {(n, wdt)}")
+            return list(self._given_masks)
+        out = []
+        for li, wdt in enumerate((512, 512, 512, 256, 128)):
+            m = torch.empty(n, wdt, dtype=F32, device=self._device)
+            ops.dropout_mask(m, self.dropout_seed, TID_DROP + 8 * self._drop_step + li, DROP_P)
+            out.append(m)
+        self._drop_step += 1
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # forward / backward on device tensors
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _sizes(h, w):
+        h1, w1 = (h + 3) // 3 + 1, (w + 3) // 3 + 1
+        return (h1, w1), (h1 - 2, w1 - 2), (h1 - 4, w1 - 4), (h1 - 6, w1 - 6)
+
+    def _bn_block(self, y, n, hc, wc, c, i, save):
+        """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift)."""
+        dev = self._device
+        p = torch.empty(n, hc - 2, wc - 2, c, dtype=F32, device=dev)
+        idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
+        partials = torch.empty(STAT_PARTS * 2 * c, dtype=torch.float64, device=dev)
+        ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
+        bn = getattr(self.visbl, f"bnorm{i}")
+        st = torch.empty(4, c, dtype=F32, device=dev)
+        ops.bn_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
+                        bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, n * (hc - 2) * (wc - 2), c,
+                        st[0], st[1], st[2], st[3])
+        bn.num_batches_tracked += 1
+        return p, idx, st
+
+    def forward_device(self, audio, visual, save: bool):
+        """audio (N,30,B) / None, visual (N,3,H,W): contiguous fp32 GPU tensors. Returns out (N,) [, ctx]."""
+        if visual.dim() != 4 or visual.shape[1] != 3:
+            raise RuntimeError(f"visual_input must be (N,3,H,W), got {tuple(visual.shape)}")
+        n, _, h, w = visual.shape
+        (h1, w1), (hp1, wp1), (hp2, wp2), (hp3, wp3) = self._sizes(h, w)
+        if hp3 < 1 or wp3 < 1:
+            raise RuntimeError(f"frames of {h}x{w} are too small for VisBl")
+        bins = l1 = l2 = 0
+        if self.audio_included:
+            if audio is None or audio.dim() != 3 or audio.shape[0] != n or audio.shape[1] != 30:
+                raise RuntimeError("audio_input must be (N,30,B) when audio_included=True")
+            bins = audio.shape[2]
+            l1 = (bins - 1) // 2 + 1
+            l2 = (l1 - 1) // 2 + 1
+        self._materialize(hp3 * wp3, l2)
+        dev = self._device
+        P = self._pflat
+        masks = self._masks(n)
+        ctx = {"n": n, "h": h, "w": w, "bins": bins, "visual": visual, "audio": audio} if save else None
+
+        # ---- VisBl, utils.py:172-195
+        y1 = torch.empty(n, h1, w1, 64, dtype=F32, device=dev)
+        ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
+        p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
+        y2 = torch.empty(n, hp1, wp1, 256, dtype=F32, device=dev)
+        ops.conv3x3_fwd(p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+        p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
+        y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
+        ops.conv3x3_fwd(p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+        p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save)
+
+        fw = 640 if self.audio_included else 512
+        voff = fw - 512
+        cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
+        mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
+        k5 = 512 * hp3 * wp3
+        ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
+                       scale=st3[2], shift=st3[3], bnC=512, dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+
+        a1 = a2 = None
+        if self.audio_included:
+            # ---- AudBl, utils.py:214-227
+            a1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
+            ops.conv1d_fwd(audio, P("audbl.conv1.weight"), P("audbl.conv1.bias"), a1, True, n, 30, bins, 64)
+            a2 = torch.empty(n, 128, l2, dtype=F32, device=dev)
+            ops.conv1d_fwd(a1, P("audbl.conv2.weight"), P("audbl.conv2.bias"), a2, True, n, 64, l1, 128)
+            ops.linear_fwd(a2.view(n, 128 * l2), P("audbl.linear3.weight"), P("audbl.linear3.bias"), cat[:, :128], relu=True,
+                           mult_out=None if mcat is None else mcat[:, :128])
+
+        # ---- fusion, utils.py:242-258, 269-270
+        hs, ms = [cat], [mcat]
+        x = cat
+        for li, (key, width) in enumerate((("0", 512), ("3", 512), ("6", 256), ("9", 128))):
+            hnext = torch.empty(n, width, dtype=F32, device=dev)
+            m = torch.empty(n, width, dtype=F32, device=dev) if save else None
+            ops.linear_fwd(x, P(f"fusion.{key}.weight"), P(f"fusion.{key}.bias"), hnext, relu=True,
+                           dropmask=masks[1 + li], mult_out=m)
+            hs.append(hnext); ms.append(m)
+            x = hnext
+        logit = torch.empty(n, dtype=F32, device=dev)
+        out = torch.empty(n, dtype=F32, device=dev)
+        ops.head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
+        if save:
+            ctx.update(y1=y1, p1=p1, idx1=idx1, st1=st1, y2=y2, p2=p2, idx2=idx2, st2=st2, y3=y3, p3=p3, idx3=idx3, st3=st3,
+                       a1=a1, a2=a2, hs=hs, ms=ms, logit=logit, out=out, l1=l1, l2=l2)
+        self.last_logit = logit
+        return out, ctx
+
+    def _block_bwd(self, dbn, ctx, i, n, hc, wc, c):
+        """BN backward + max-pool backward + ReLU backward of block i. dbn = grad wrt the BN output (N,hc-2,wc-2,c).
+        Returns dy (N,hc,wc,c) = grad wrt the conv's pre-ReLU output; writes dgamma, dbeta, dbias into the grad arena."""
+        dev = self._device
+        G = self._gflat
+        p, idx, y, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"y{i}"], ctx[f"st{i}"]
+        npix = n * (hc - 2) * (wc - 2)
+        partials = torch.empty(STAT_PARTS * 2 * c, dtype=torch.float64, device=dev)
+        ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, npix, c)
+        coef3 = torch.empty(3 * c, dtype=F32, device=dev)
+        ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
+                            G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
+        dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
+        ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, partials, n, hc, wc, c)
+        ops.partials_sum(partials, STAT_PARTS, c, c, G(f"visbl.conv{i}.bias"))
+        return dy
+
+    def backward_device(self, ctx, dout, on_bucket=None):
+        """dout (N,) GPU. Fills the gradient arena (every slot is overwritten). `on_bucket(k)` is called when
+        bucket k of ddp.bucket_slices() is complete (0: fusion+audbl+linear5.bias, 1: linear5.weight, 2: rest)."""
+        self._ensure_garena()
+        dev = self._device
+        n, h, w = ctx["n"], ctx["h"], ctx["w"]
+        (h1, w1), (hp1, wp1), (hp2, wp2), (hp3, wp3) = self._sizes(h, w)
+        P, G = self._pflat, self._gflat
+        hs, ms = ctx["hs"], ctx["ms"]
+
+        # head + fusion MLP (reverse of utils.py:242-258)
+        dz = torch.empty(n, 128, dtype=F32, device=dev)
+        ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
+        for key, li in (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
+            x_in, m_in = hs[li], ms[li]
+            ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"))
+            ops.colsum(dz, G(f"fusion.{key}.bias"))
+            dprev = torch.empty(n, x_in.shape[1], dtype=F32, device=dev)
+            ops.linear_bwd_dx(dz, P(f"fusion.{key}.weight"), dprev, mult=m_in)
+            dz = dprev
+        voff = dz.shape[1] - 512
+        dz5 = dz[:, voff:]                                     # grad wrt linear5 pre-activation
+
+        if self.audio_included:
+            l1, l2, bins = ctx["l1"], ctx["l2"], ctx["bins"]
+            dza = dz[:, :128]
+            a2f = ctx["a2"].view(n, 128 * l2)
+            ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"))
+            ops.colsum(dza, G("audbl.linear3.bias"))
+            da2 = torch.empty(n, 128 * l2, dtype=F32, device=dev)
+            ops.linear_bwd_dx(dza, P("audbl.linear3.weight"), da2, mult=None)
+            ops.relu_bwd(da2, a2f, da2)
+            da1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
+            ops.conv1d_bwd(ctx["a1"], da2, P("audbl.conv2.weight"), da1, G("audbl.conv2.weight"), G("audbl.conv2.bias"), n, 64, l1, 128)
+            ops.relu_bwd(da1, ctx["a1"], da1)
+            ops.conv1d_bwd(ctx["audio"], da1, P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
+        ops.colsum(dz5, G("visbl.linear5.bias"))
+        if on_bucket:
+            on_bucket(0)
+
+        # linear5 (utils.py:191): dW straight into the arena, dX = grad wrt bnorm3's output
+        k5 = 512 * hp3 * wp3
+        p3f = ctx["p3"].view(n, k5)
+        st3 = ctx["st3"]
+        ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512)
+        if on_bucket:
+            on_bucket(1)
+        dbn3 = torch.empty(n, hp3, wp3, 512, dtype=F32, device=dev)
+        ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
+
+        # block 3 (utils.py:184-187)
+        dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
+        del dbn3
+        st2 = ctx["st2"]
+        ops.conv3x3_wgrad(ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+        wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
+        ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
+        dbn2 = torch.empty(n, hp2, wp2, 256, dtype=F32, device=dev)
+        ops.conv3x3_fwd(dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
+        del dy3
+
+        # block 2 (utils.py:179-182)
+        dy2 = self._block_bwd(dbn2, ctx, 2, n, hp1, wp1, 256)
+        del dbn2
+        st1 = ctx["st1"]
+        ops.conv3x3_wgrad(ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+        wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
+        ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
+        dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
+        ops.conv3x3_fwd(dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
+        del dy2
+
+        # block 1 (utils.py:174-177); conv1's input needs no gradient
+        dy1 = self._block_bwd(dbn1, ctx, 1, n, h1, w1, 64)
+        ops.conv1_wgrad(ctx["visual"], dy1, G("visbl.conv1.weight"), G("visbl.conv1.bias"), n, h, w)
+        if on_bucket:
+            on_bucket(2)
+
+    # ------------------------------------------------------------------------------------------
+    # drop-in surface: model(audio_input, visual_input)
+    # ------------------------------------------------------------------------------------------
+    def _to_device_inputs(self, audio_input, visual_input):
+        self._require_device()
+        if not torch.is_tensor(visual_input):
+            raise TypeError("visual_input must be a tensor (N,3,H,W)")
+        src_dev = visual_input.device
+        vis = visual_input.detach().to(device=self._device, dtype=F32).contiguous()
+        aud = None
+        if self.audio_included:
+            if not torch.is_tensor(audio_input):
+                raise TypeError("audio_input must be a tensor (N,30,B) when audio_included=True")
+            aud = audio_input.detach().to(device=self._device, dtype=F32).contiguous()
+        return aud, vis, src_dev
+
+    def forward(self, audio_input, visual_input):
+        """utils.py:260-272. Accepts the CPU tensors the reference's scripts pass (H2D inside) or GPU tensors; the
+        (N,1) result is returned on the inputs' device, attached to autograd when grad mode is on."""
+        aud, vis, src_dev = self._to_device_inputs(audio_input, visual_input)
+        need_grad = torch.is_grad_enabled()
+        if not self._materialized:
+            # first forward materialises the Lazy parameters (shapes depend on H, W, B)
+            (_, _), _, _, (hp3, wp3) = self._sizes(vis.shape[2], vis.shape[3])
+            l2 = 0
+            if self.audio_included:
+                l2 = (((aud.shape[2] - 1) // 2 + 1) - 1) // 2 + 1
+            self._materialize(hp3 * wp3, l2)
+        if not need_grad:
+            out, _ = self.forward_device(aud, vis, save=False)
+            return out.view(-1, 1).to(src_dev)
+        params = [getattr(*self._module_of(s.name)) for s in self._specs]
+        return _AVMFunction.apply(self, aud, vis, src_dev, *params)
+
+    # ------------------------------------------------------------------------------------------
+    # device-resident fused train step: forward, broadcast MSE, backward, Adam
+    # ------------------------------------------------------------------------------------------
+    def train_step(self, audio, visual, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """main.py:187-193 on GPU tensors. Returns (loss (1,), pred (N,)) as GPU tensors, no host sync."""
+        out, ctx = self.forward_device(audio, visual, save=True)
+        n = out.numel()
+        loss = torch.empty(1, dtype=F32, device=self._device)
+        dout = torch.empty(n, dtype=F32, device=self._device)
+        ops.mse_bcast(out, labels, loss, dout)
+        sync = self.grad_sync
+        self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)
+        scale = 1.0
+        if sync is not None:
+            scale = sync.finish(self)
+        self.adam_step(lr, betas, eps, scale)
+        return loss, out
+
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193)."""
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self._arena)
+            self._adam_v = torch.zeros_like(self._arena)
+        self._adam_t += 1
+        ops.adam_step(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._adam_t, grad_scale)
+
+    def grad_of(self, name) -> torch.Tensor:
+        """Gradient of a parameter as a strided view with the reference's logical shape (linear5: (512, C*HW) copy)."""
+        s = self.spec(name)
+        v = self._view(self._garena, s)
+        return v.reshape(s.shape[0], -1) if s.kind == "lin5" else v
+
+    def param_of(self, name) -> torch.Tensor:
+        s = self.spec(name)
+        v = self._view(self._arena, s)
+        return v.reshape(s.shape[0], -1) if s.kind == "lin5" else v
+
+
+class _AVMFunction(torch.autograd.Function):
+    """Couples the HIP forward/backward to autograd so `loss.backward()` fills `.grad` of ordinary
+    nn.Parameters (SURVEY.md §8(b) "Train step" (i)). Gradients are strided views of the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, model, aud, vis, src_dev, *params):
+        out, saved = model.forward_device(aud, vis, save=True)
+        ctx.model, ctx.saved, ctx.src_dev = model, saved, src_dev
+        return out.view(-1, 1).to(src_dev)
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, saved = ctx.model, ctx.saved
+        # a previous backward's .grad may alias the arena we are about to overwrite (no zero_grad in between)
+        for s in model._specs:
+            prm = getattr(*model._module_of(s.name))
+            if prm.grad is not None and model._garena is not None and \
+                    prm.grad.untyped_storage().data_ptr() == model._garena.untyped_storage().data_ptr():
+                prm.grad = prm.grad.clone()
+        dout = gout.detach().to(device=model._device, dtype=F32).contiguous().view(-1)
+        model.backward_device(saved, dout)
+        ctx.saved = None
+        grads = [model._view(model._garena, s) for s in model._specs]
+        return (None, None, None, None, *grads)

@@ -1,0 +1,184 @@
+// VisBl conv1: Conv2d(3 -> 64, k3, stride 3, pad 3) + bias + ReLU, and its weight gradient.
+// /root/reference/utils.py:151-152, 174-175.
+//
+// K = 27 per output: this is HBM/LDS-bound direct convolution, not matrix-core work.
+// Stride = kernel = 3, so the 3x3x3 input patches of neighbouring outputs are disjoint: every input
+// element is read exactly once. Input is the reference's NCHW frame tensor (read coalesced along W);
+// output is NHWC for the implicit-GEMM blocks that follow.
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+constexpr int CO = 64, KP = 27;
+constexpr int WG_PARTS = 512;   // blocks (= partial rows) of the weight-gradient kernel
+
+__device__ __forceinline__ int conv1_out(int x) { return (x + 3) / 3 + 1; }
+
+// patch element k = (kh*3 + kw)*3 + ci  (OHWI order)  of output pixel (n, oh, ow); 0 in the padding
+__device__ __forceinline__ float patch_at(const float* __restrict__ x, int n, int oh, int ow, int k, int H, int W) {
+    const int ci = k % 3, t = k / 3;
+    const int kh = t / 3, kw = t - 3 * kh;
+    const int ih = 3 * oh - 3 + kh, iw = 3 * ow - 3 + kw;
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        return x[(((int64_t)n * 3 + ci) * H + ih) * W + iw];
+    return 0.f;
+}
+
+// 256 threads: 64 pixels x 4 groups of 16 output channels
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int N, int H, int W, int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) float ws[KP][CO];
+    __shared__ float patch[64][KP + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < KP * CO; i += 256) {
+        const int co = i / KP, k = i - co * KP;      // w is [co][kh][kw][ci]
+        ws[k][co] = w[i];
+    }
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    const int pl = tid >> 2, cg = tid & 3;
+    for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < npix; p0 += (int64_t)gridDim.x * 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * KP; i += 256) {
+            const int pp = i / KP, k = i - pp * KP;
+            const int64_t pix = p0 + pp;
+            float v = 0.f;
+            if (pix < npix) {
+                const int ow = (int)(pix % Wo);
+                const int oh = (int)((pix / Wo) % Ho);
+                const int n = (int)(pix / ((int64_t)Wo * Ho));
+                v = patch_at(x, n, oh, ow, k, H, W);
+            }
+            patch[pp][k] = v;
+        }
+        __syncthreads();
+        const int64_t pix = p0 + pl;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const float xv = patch[pl][k];
+            const float4* wp = reinterpret_cast<const float4*>(&ws[k][cg * 16]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wv = wp[q];
+                acc[4 * q + 0] = fmaf(xv, wv.x, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(xv, wv.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(xv, wv.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(xv, wv.w, acc[4 * q + 3]);
+            }
+        }
+        if (pix < npix) {
+            float4* o = reinterpret_cast<float4*>(y + pix * CO + cg * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+        }
+    }
+}
+
+// dW[co][k] = sum_pix dy[pix][co] * patch[pix][k]; db[co] = sum_pix dy[pix][co].
+// thread = (co = tid & 63, kg = tid >> 6): k in [7*kg, 7*kg + 7); partial row per block, summed by a second kernel.
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ partial, int N, int H, int W, int Ho, int Wo) {
+    __shared__ float dys[64][CO + 1];
+    __shared__ float patch[64][KP + 1];
+    const int tid = threadIdx.x;
+    const int co = tid & 63, kg = tid >> 6;
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < npix; p0 += (int64_t)gridDim.x * 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * CO; i += 256) {
+            const int pp = i >> 6, c = i & 63;
+            const int64_t pix = p0 + pp;
+            dys[pp][c] = pix < npix ? dy[pix * CO + c] : 0.f;
+        }
+        for (int i = tid; i < 64 * KP; i += 256) {
+            const int pp = i / KP, k = i - pp * KP;
+            const int64_t pix = p0 + pp;
+            float v = 0.f;
+            if (pix < npix) {
+                const int ow = (int)(pix % Wo);
+                const int oh = (int)((pix / Wo) % Ho);
+                const int n = (int)(pix / ((int64_t)Wo * Ho));
+                v = patch_at(x, n, oh, ow, k, H, W);
+            }
+            patch[pp][k] = v;
+        }
+        if (tid < 64) patch[tid][KP] = 0.f;
+        __syncthreads();
+#pragma unroll 4
+        for (int pp = 0; pp < 64; ++pp) {
+            const float d = dys[pp][co];
+            accb += d;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int k = 7 * kg + j;
+                acc[j] = fmaf(d, patch[pp][k < KP ? k : KP], acc[j]);   // column KP is zero padding
+            }
+        }
+    }
+    float* row = partial + (int64_t)blockIdx.x * (CO * KP + CO);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 7 * kg + j;
+        if (k < KP) row[co * KP + k] = acc[j];
+    }
+    if (kg == 0) row[CO * KP + co] = accb;
+}
+
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts,
+                                                                float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CO * KP + CO) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)partial[(int64_t)p * (CO * KP + CO) + i];
+    if (i < CO * KP) dw[i] = (float)s;
+    else if (db) db[i - CO * KP] = (float)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_conv1_fwd(const float* x_nchw, const float* w_ohwi, const float* bias, float* y_nhwc,
+                      int N, int H, int W, void* stream) {
+    GN_REQUIRE(x_nchw && w_ohwi && bias && y_nhwc, GOALNET_E_NULL, "conv1_fwd: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0, GOALNET_E_SHAPE, "conv1_fwd: non-positive dim");
+    GN_REQUIRE(aligned16(y_nhwc), GOALNET_E_ALIGN, "conv1_fwd: output must be 16-byte aligned");
+    const int Ho = (H + 3) / 3 + 1, Wo = (W + 3) / 3 + 1;
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    int64_t blocks = (npix + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_ohwi, bias,
+                       y_nhwc, N, H, W, Ho, Wo);
+    GN_LAUNCH_CHECK("conv1_fwd");
+    return 0;
+}
+
+size_t goalnet_conv1_wgrad_ws_bytes(int N, int H, int W) {
+    (void)N; (void)H; (void)W;
+    return (size_t)WG_PARTS * (CO * KP + CO) * sizeof(float);
+}
+
+int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohwi, float* dbias,
+                        void* ws, size_t ws_bytes, int N, int H, int W, void* stream) {
+    GN_REQUIRE(x_nchw && dy_nhwc && dw_ohwi && ws, GOALNET_E_NULL, "conv1_wgrad: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0, GOALNET_E_SHAPE, "conv1_wgrad: non-positive dim");
+    GN_REQUIRE(ws_bytes >= goalnet_conv1_wgrad_ws_bytes(N, H, W), GOALNET_E_WORKSPACE, "conv1_wgrad: workspace too small");
+    const int Ho = (H + 3) / 3 + 1, Wo = (W + 3) / 3 + 1;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(WG_PARTS), dim3(256), 0, (hipStream_t)stream, x_nchw, dy_nhwc,
+                       (float*)ws, N, H, W, Ho, Wo);
+    GN_LAUNCH_CHECK("conv1_wgrad");
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((CO * KP + CO + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, WG_PARTS, dw_ohwi, dbias);
+    GN_LAUNCH_CHECK("conv1_wgrad.reduce");
+    return 0;
+}
+
+}  // extern "C"

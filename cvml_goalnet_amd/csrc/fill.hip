@@ -1,0 +1,65 @@
+// Synthetic data and dropout-mask generators: the device twin of cvml_goalnet_amd/synth.py
+// (counter-based splitmix64). Element i of stream `tensor_id` depends only on
+// (seed, tensor_id, i), so any launch geometry produces the same bits as numpy.
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint32_t tid) {
+    return mix64(seed + (uint64_t)(tid + 1u) * 0xD1342543DE82EF95ull);
+}
+__device__ __forceinline__ float unit24(uint64_t key, int64_t i) {
+    const uint64_t b = mix64(key + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull);
+    return (float)(uint32_t)(b >> 40) * 5.9604644775390625e-08f;   // 2^-24, exact
+}
+
+__global__ __launch_bounds__(256) void fill_uniform_kernel(float* dst, int64_t n, uint64_t key, float lo, float span) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = __fadd_rn(lo, __fmul_rn(span, unit24(key, i)));   // two roundings, as numpy does (no FMA)
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* dst, int64_t n, uint64_t key, float p, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = unit24(key, i) >= p ? scale : 0.f;
+}
+
+unsigned grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_fill_uniform(float* dst, int64_t n, uint64_t seed, uint32_t tensor_id, float lo, float hi, void* stream) {
+    GN_REQUIRE(dst, GOALNET_E_NULL, "fill_uniform: null pointer");
+    GN_REQUIRE(n >= 0, GOALNET_E_SHAPE, "fill_uniform: negative count");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, n,
+                       stream_key(seed, tensor_id), lo, hi - lo);
+    GN_LAUNCH_CHECK("fill_uniform");
+    return 0;
+}
+
+int goalnet_dropout_mask(float* dst, int64_t n, uint64_t seed, uint32_t tensor_id, float p, void* stream) {
+    GN_REQUIRE(dst, GOALNET_E_NULL, "dropout_mask: null pointer");
+    GN_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, GOALNET_E_SHAPE, "dropout_mask: bad count or p");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, n,
+                       stream_key(seed, tensor_id), p, 1.0f / (1.0f - p));
+    GN_LAUNCH_CHECK("dropout_mask");
+    return 0;
+}
+
+}  // extern "C"

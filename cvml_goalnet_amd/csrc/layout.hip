@@ -1,0 +1,68 @@
+// Layout converters between the reference's torch-native layouts (OIHW weights, NCHW activations,
+// NCHW-flatten linear5 columns; SURVEY.md §8(b) "Persistence") and the device layouts (OHWI, NHWC).
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+// [B][R][C] -> [B][C][R] through a padded 32x32 LDS tile; both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_inner_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int64_t R, int64_t C, int64_t tiles_c) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int64_t tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float* s = src + b * R * C;
+    float* d = dst + b * R * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = tr * 32 + ty + 8 * i, c = tc * 32 + tx;
+        if (r < R && c < C) tile[ty + 8 * i][tx] = s[r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t c = tc * 32 + ty + 8 * i, r = tr * 32 + tx;
+        if (r < R && c < C) d[c * R + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin) {
+    const int total = Cout * Cin * 9;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        // i indexes wt[ci][t'][co]
+        const int co = i % Cout;
+        const int t = (i / Cout) % 9;
+        const int ci = i / (Cout * 9);
+        wt[i] = w[((int64_t)co * 9 + (8 - t)) * Cin + ci];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_transpose_inner(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream) {
+    GN_REQUIRE(src && dst, GOALNET_E_NULL, "transpose_inner: null pointer");
+    GN_REQUIRE(B > 0 && R > 0 && C > 0 && B <= 65535, GOALNET_E_SHAPE, "transpose_inner: bad dims (B <= 65535)");
+    const int64_t tiles_r = (R + 31) / 32, tiles_c = (C + 31) / 32;
+    GN_REQUIRE(tiles_r * tiles_c < (1ll << 31), GOALNET_E_SHAPE, "transpose_inner: too many tiles");
+    hipLaunchKernelGGL(transpose_inner_kernel, dim3((unsigned)(tiles_r * tiles_c), 1, (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, R, C, tiles_c);
+    GN_LAUNCH_CHECK("transpose_inner");
+    return 0;
+}
+
+int goalnet_conv3x3_weight_flip(const float* w_ohwi, float* wt, int Cout, int Cin, void* stream) {
+    GN_REQUIRE(w_ohwi && wt, GOALNET_E_NULL, "conv3x3_weight_flip: null pointer");
+    GN_REQUIRE(Cout > 0 && Cin > 0 && (int64_t)Cout * Cin * 9 < (1ll << 30), GOALNET_E_SHAPE, "conv3x3_weight_flip: bad dims");
+    const int total = Cout * Cin * 9;
+    int blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(weight_flip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, wt, Cout, Cin);
+    GN_LAUNCH_CHECK("conv3x3_weight_flip");
+    return 0;
+}
+
+}  // extern "C"

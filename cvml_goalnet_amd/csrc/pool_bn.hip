@@ -1,0 +1,294 @@
+// MaxPool2d(3, stride 1) + train-mode BatchNorm2d statistics, and their backward pass.
+// /root/reference/utils.py:153-154, 158-159, 163-164 (forward), autograd of main.py:192 (backward).
+//
+// All of these are HBM-bound passes over NHWC tensors (float4 = 4 channels per lane, lanes of a wave walk
+// the channel dimension, so every access is a full coalesced line). The BatchNorm *apply* never gets its
+// own pass: it is folded into the operand load of the next GEMM (gemm_f32.hip), because training-mode
+// statistics are only known after the whole pooled tensor has been produced (SURVEY.md §7 "Hard parts").
+//
+// Statistics are accumulated in fp64 and reduced through a fixed number (GOALNET_STAT_PARTS) of per-block
+// partial rows that a second kernel sums in a fixed order: deterministic, and accurate to the level of
+// ATen's CPU implementation (which accumulates float statistics in double).
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+constexpr int PARTS = GOALNET_STAT_PARTS;
+
+struct d4 { double x, y, z, w; };
+
+// block-level reduction of per-thread (4 channels x NV values) doubles over the threads that share a
+// channel group g = tid % G; result written by the threads with tid < G.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NV][4], int G, int tid, double* smem,
+                                                   double* out_row, int64_t out_stride, int C) {
+    // smem: [256][NV*4] doubles
+#pragma unroll
+    for (int a = 0; a < NV; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) smem[tid * (NV * 4) + a * 4 + c] = v[a][c];
+    __syncthreads();
+    if (tid < G) {
+        const int reps = 256 / G;
+#pragma unroll
+        for (int a = 0; a < NV; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int rp = 0; rp < reps; ++rp) s += smem[(rp * G + tid) * (NV * 4) + a * 4 + c];
+                out_row[a * out_stride + tid * 4 + c] = s;
+            }
+    }
+    (void)C;
+}
+
+// ---- forward: p = maxpool3x3s1(y), idx = argmax (first maximum in kh,kw scan order, NaN wins, as ATen's
+// max_pool2d CPU kernel), partial sums of p and p*p per channel.
+__global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __restrict__ y, float* __restrict__ p,
+                                                              uint8_t* __restrict__ idx, double* __restrict__ partials,
+                                                              int N, int Hc, int Wc, int C) {
+    __shared__ double smem[256 * 8];
+    const int tid = threadIdx.x;
+    const int G = C >> 2;                 // channel groups of 4; G divides 256
+    const int g = tid % G, pl = tid / G;
+    const int ppi = 256 / G;              // pixels per block iteration
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    const int64_t npix = (int64_t)N * Hp * Wp;
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int64_t pix = (int64_t)blockIdx.x * ppi + pl; pix < npix; pix += (int64_t)gridDim.x * ppi) {
+        const int pw = (int)(pix % Wp);
+        const int ph = (int)((pix / Wp) % Hp);
+        const int64_t n = pix / ((int64_t)Wp * Hp);
+        const float* src = y + ((n * Hc + ph) * Wc + pw) * C + g * 4;
+        float4 v[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                v[kh * 3 + kw] = *reinterpret_cast<const float4*>(src + ((int64_t)kh * Wc + kw) * C);
+        float4 best = v[0];
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            if (v[k].x > best.x || v[k].x != v[k].x) { best.x = v[k].x; bi[0] = k; }
+            if (v[k].y > best.y || v[k].y != v[k].y) { best.y = v[k].y; bi[1] = k; }
+            if (v[k].z > best.z || v[k].z != v[k].z) { best.z = v[k].z; bi[2] = k; }
+            if (v[k].w > best.w || v[k].w != v[k].w) { best.w = v[k].w; bi[3] = k; }
+        }
+        *reinterpret_cast<float4*>(p + pix * C + g * 4) = best;
+        if (idx) *reinterpret_cast<uint32_t*>(idx + pix * C + g * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
+        acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
+        acc[0][2] += (double)best.z; acc[1][2] += (double)best.z * (double)best.z;
+        acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
+    }
+    block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, float momentum, float eps, double count,
+                                                         int C, float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int pt = 0; pt < PARTS; ++pt) {
+        s += partials[(int64_t)pt * 2 * C + c];
+        q += partials[(int64_t)pt * 2 * C + C + c];
+    }
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = fm;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - fm * sc;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// ---- backward phase 1: partial sums of dz and dz * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           double* __restrict__ partials, int64_t npix, int C) {
+    __shared__ double smem[256 * 8];
+    const int tid = threadIdx.x;
+    const int G = C >> 2;
+    const int g = tid % G, pl = tid / G;
+    const int ppi = 256 / G;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + g * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + g * 4);
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int64_t pix = (int64_t)blockIdx.x * ppi + pl; pix < npix; pix += (int64_t)gridDim.x * ppi) {
+        const float4 d = *reinterpret_cast<const float4*>(dz + pix * C + g * 4);
+        const float4 x = *reinterpret_cast<const float4*>(p + pix * C + g * 4);
+        acc[0][0] += (double)d.x; acc[1][0] += (double)d.x * (double)((x.x - mu.x) * is.x);
+        acc[0][1] += (double)d.y; acc[1][1] += (double)d.y * (double)((x.y - mu.y) * is.y);
+        acc[0][2] += (double)d.z; acc[1][2] += (double)d.z * (double)((x.z - mu.z) * is.z);
+        acc[0][3] += (double)d.w; acc[1][3] += (double)d.w * (double)((x.w - mu.w) * is.w);
+    }
+    block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             double count, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ coef3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int pt = 0; pt < PARTS; ++pt) {
+        s += partials[(int64_t)pt * 2 * C + c];
+        q += partials[(int64_t)pt * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
+    const double a = (double)gamma[c] * (double)invstd[c];
+    const double m1 = s / count, m2 = q / count;
+    const double b = -a * m2 * (double)invstd[c];
+    const double cc = -a * m1 - b * (double)mean[c];
+    coef3[c] = (float)a;
+    coef3[C + c] = (float)b;
+    coef3[2 * C + c] = (float)cc;
+}
+
+// ---- backward phase 3: dy[n,h,w,c] = relu'(y) * sum over the (<= 9) pooling windows that contain (h,w) and
+// whose argmax is (h,w) of dp[window], dp = a*dz + b*p + cc. A gather (no atomics, deterministic).
+__global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                        const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                                        const float* __restrict__ coef3, float* __restrict__ dy,
+                                                        double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
+    __shared__ double smem[256 * 4];
+    const int tid = threadIdx.x;
+    const int G = C >> 2;
+    const int g = tid % G, pl = tid / G;
+    const int ppi = 256 / G;
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    const int64_t npix = (int64_t)N * Hc * Wc;
+    const float4 ca = *reinterpret_cast<const float4*>(coef3 + g * 4);
+    const float4 cb = *reinterpret_cast<const float4*>(coef3 + C + g * 4);
+    const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + g * 4);
+    double accb[1][4] = {{0, 0, 0, 0}};
+    for (int64_t pix = (int64_t)blockIdx.x * ppi + pl; pix < npix; pix += (int64_t)gridDim.x * ppi) {
+        const int w = (int)(pix % Wc);
+        const int h = (int)((pix / Wc) % Hc);
+        const int64_t n = pix / ((int64_t)Wc * Hc);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int ph = h - dh, pw = w - dw;                 // window origin; this pixel is tap (dh, dw)
+                const bool ok = (unsigned)ph < (unsigned)Hp && (unsigned)pw < (unsigned)Wp;
+                const int phc = ok ? ph : 0, pwc = ok ? pw : 0;     // clamped: loads stay unconditional
+                const int64_t q = ((n * Hp + phc) * Wp + pwc) * C + g * 4;
+                const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + q);
+                const float4 d = *reinterpret_cast<const float4*>(dz + q);
+                const float4 x = *reinterpret_cast<const float4*>(p + q);
+                const unsigned k = dh * 3 + dw;
+                acc.x += (ok && (ii & 0xffu) == k) ? fmaf(ca.x, d.x, fmaf(cb.x, x.x, cc.x)) : 0.f;
+                acc.y += (ok && ((ii >> 8) & 0xffu) == k) ? fmaf(ca.y, d.y, fmaf(cb.y, x.y, cc.y)) : 0.f;
+                acc.z += (ok && ((ii >> 16) & 0xffu) == k) ? fmaf(ca.z, d.z, fmaf(cb.z, x.z, cc.z)) : 0.f;
+                acc.w += (ok && (ii >> 24) == k) ? fmaf(ca.w, d.w, fmaf(cb.w, x.w, cc.w)) : 0.f;
+            }
+        const float4 yy = *reinterpret_cast<const float4*>(y + pix * C + g * 4);
+        acc.x = yy.x > 0.f ? acc.x : 0.f;
+        acc.y = yy.y > 0.f ? acc.y : 0.f;
+        acc.z = yy.z > 0.f ? acc.z : 0.f;
+        acc.w = yy.w > 0.f ? acc.w : 0.f;
+        *reinterpret_cast<float4*>(dy + pix * C + g * 4) = acc;
+        accb[0][0] += (double)acc.x; accb[0][1] += (double)acc.y; accb[0][2] += (double)acc.z; accb[0][3] += (double)acc.w;
+    }
+    block_reduce_store<1>(accb, G, tid, smem, dbias_partials + (int64_t)blockIdx.x * C, C, C);
+}
+
+__global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restrict__ partials, int nparts, int64_t stride,
+                                                          int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int pt = 0; pt < nparts; ++pt) s += partials[(int64_t)pt * stride + c];
+    out[c] = (float)s;
+}
+
+bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >> 2)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials,
+                             int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(y && p && partials, GOALNET_E_NULL, "pool_bnstats_fwd: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3, GOALNET_E_SHAPE, "pool_bnstats_fwd: need Hc, Wc >= 3");
+    GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bnstats_fwd: C=%d must be 4*2^k, <= 1024", C);
+    GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
+               "pool_bnstats_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("pool_bnstats_fwd");
+    return 0;
+}
+
+int goalnet_bn_finalize(const double* partials, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int64_t count,
+                        int C, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    GN_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift, GOALNET_E_NULL, "bn_finalize: null pointer");
+    GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "bn_finalize: running stats must both be set or both NULL");
+    GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_finalize: bad dims");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, gamma, beta,
+                       running_mean, running_var, momentum, eps, (double)count, C, mean, invstd, scale, shift);
+    GN_LAUNCH_CHECK("bn_finalize");
+    return 0;
+}
+
+int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
+                          double* partials, int64_t npix, int C, void* stream) {
+    GN_REQUIRE(dz && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce: null pointer");
+    GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
+    GN_LAUNCH_CHECK("bn_bwd_reduce");
+    return 0;
+}
+
+int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const float* mean, const float* invstd,
+                            int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream) {
+    GN_REQUIRE(partials && gamma && mean && invstd && dgamma && dbeta && coef3, GOALNET_E_NULL, "bn_bwd_finalize: null pointer");
+    GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_bwd_finalize: bad dims");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, gamma, mean,
+                       invstd, (double)count, C, dgamma, dbeta, coef3);
+    GN_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+                       float* dy, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && idx && y && coef3 && dy && dbias_partials, GOALNET_E_NULL, "bnpool_bwd: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd: alignment");
+    hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
+                       dbias_partials, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bnpool_bwd");
+    return 0;
+}
+
+int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream) {
+    GN_REQUIRE(partials && out, GOALNET_E_NULL, "partials_sum: null pointer");
+    GN_REQUIRE(nparts > 0 && C > 0 && stride >= C, GOALNET_E_SHAPE, "partials_sum: bad dims");
+    hipLaunchKernelGGL(partials_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
+    GN_LAUNCH_CHECK("partials_sum");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,377 @@
+// The small ops of the hot path: AudBl's two Conv1d layers, the 128 -> 1 head with Sigmoid and 4y+1,
+// the broadcast MSE loss, bias-gradient column sums, elementwise helpers and the fused Adam step.
+// /root/reference/utils.py:203-227 (AudBl), 255-256, 270 (head), main.py:68-70, 191-193 (loss, Adam).
+//
+// Together they are < 1 % of the model's arithmetic and, except Adam, touch
+// kilobytes to a few megabytes: they are written for correctness and determinism, not for a roofline.
+// Adam is the exception: one pass over the flat parameter arena at 28 B/parameter (HBM-bound), it was
+// 57 % of the reference's step at its own sub-batch size.
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Conv1d (kernel 3), NCL layout. One thread per output element.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int relu, float* __restrict__ y,
+                                                        int N, int Cin, int L, int Cout, int Lo, int stride, int pad) {
+    const int64_t total = (int64_t)N * Cout * Lo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lo = (int)(i % Lo);
+        const int co = (int)((i / Lo) % Cout);
+        const int64_t n = i / ((int64_t)Lo * Cout);
+        const float* xs = x + n * Cin * L;
+        const float* ws = w + (int64_t)co * Cin * 3;
+        float acc = b[co];
+        const int l0 = stride * lo - pad;
+        for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int l = l0 + k;
+                if ((unsigned)l < (unsigned)L) acc = fmaf(xs[ci * L + l], ws[ci * 3 + k], acc);
+            }
+        }
+        y[i] = relu ? fmaxf(acc, 0.f) : acc;
+    }
+}
+
+// dx[n][ci][l] = sum_{co,k : stride*lo - pad + k = l} dz[n][co][lo] * w[co][ci][k]
+__global__ __launch_bounds__(256) void conv1d_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                       float* __restrict__ dx, int N, int Cin, int L, int Cout, int Lo,
+                                                       int stride, int pad) {
+    const int64_t total = (int64_t)N * Cin * L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i % L);
+        const int ci = (int)((i / L) % Cin);
+        const int64_t n = i / ((int64_t)L * Cin);
+        const float* dzs = dz + n * Cout * Lo;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = l + pad - k;
+            if (t < 0 || t % stride != 0) continue;
+            const int lo = t / stride;
+            if (lo >= Lo) continue;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(dzs[co * Lo + lo], w[((int64_t)co * Cin + ci) * 3 + k], acc);
+        }
+        dx[i] = acc;
+    }
+}
+
+// dw[co][ci][k] = sum_{n,lo} dz[n][co][lo] * x[n][ci][stride*lo - pad + k]; one block per (co, ci), the 256
+// threads split the frames, fp64 block reduction (deterministic).
+__global__ __launch_bounds__(256) void conv1d_dw_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                       float* __restrict__ dw, int N, int Cin, int L, int Cout, int Lo,
+                                                       int stride, int pad) {
+    __shared__ double red[4][3];
+    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* xs = x + ((int64_t)n * Cin + ci) * L;
+        const float* ds = dz + ((int64_t)n * Cout + co) * Lo;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int lo = 0; lo < Lo; ++lo) {
+            const float d = ds[lo];
+            const int l0 = stride * lo - pad;
+            if ((unsigned)(l0) < (unsigned)L) s0 = fmaf(d, xs[l0], s0);
+            if ((unsigned)(l0 + 1) < (unsigned)L) s1 = fmaf(d, xs[l0 + 1], s1);
+            if ((unsigned)(l0 + 2) < (unsigned)L) s2 = fmaf(d, xs[l0 + 2], s2);
+        }
+        a0 += s0; a1 += s1; a2 += s2;
+    }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = a0; red[wv][1] = a1; red[wv][2] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        dw[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+            (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// db[co] = sum_{n,lo} dz[n][co][lo]; one block per co
+__global__ __launch_bounds__(256) void conv1d_db_kernel(const float* __restrict__ dz, float* __restrict__ db, int N, int Cout, int Lo) {
+    __shared__ double red[4];
+    const int co = blockIdx.x;
+    double a = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* ds = dz + ((int64_t)n * Cout + co) * Lo;
+        float s = 0.f;
+        for (int lo = 0; lo < Lo; ++lo) s += ds[lo];
+        a += s;
+    }
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) db[co] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dz, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ m, int64_t ldm,
+                                                 float* __restrict__ y, int64_t ldy, int M, int J) {
+    const int64_t total = (int64_t)M * J;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / J;
+        const int c = (int)(i - r * J);
+        y[r * ldy + c] = x[r * ldx + c] * m[r * ldm + c];
+    }
+}
+
+// out[j] = sum_m x[m][j]: block = 32 columns x 8 row lanes, fp64 accumulation
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int M, int J, float* __restrict__ out) {
+    __shared__ double red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    double a = 0.0;
+    if (col < J)
+        for (int m = ry; m < M; m += 8) a += (double)x[(int64_t)m * ldx + col];
+    red[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && col < J) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += red[i][cx];
+        out[col] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: z = h . w + b ; out = 4 * sigmoid(z) + 1.  One wave per frame.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ h, int64_t ldh, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ logit,
+                                                      float* __restrict__ out, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(h[(int64_t)n * ldh + k], w[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float z = acc + b[0];
+        if (logit) logit[n] = z;
+        out[n] = 4.f / (1.f + expf(-z)) + 1.f;
+    }
+}
+
+__device__ __forceinline__ float dlogit_of(float dout, float out) {
+    // d/dz (4*sigmoid(z) + 1) = 4 s (1 - s), s = (out - 1) / 4
+    const float s = (out - 1.f) * 0.25f;
+    return dout * 4.f * s * (1.f - s);
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                         const float* __restrict__ w, const float* __restrict__ mult, int64_t ldmult,
+                                                         float* __restrict__ dh, int64_t lddh, int N, int K) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / K;
+        const int k = (int)(i - n * K);
+        float v = dlogit_of(dout[n], out[n]) * w[k];
+        if (mult) v *= mult[n * ldmult + k];
+        dh[n * lddh + k] = v;
+    }
+}
+
+// dw[k] = sum_n dlogit[n] h[n][k]; db = sum_n dlogit[n].  Thread k (K <= 1024), plus thread K for db.
+__global__ __launch_bounds__(1024) void head_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                          const float* __restrict__ h, int64_t ldh, float* __restrict__ dw,
+                                                          float* __restrict__ db, int N, int K) {
+    const int k = threadIdx.x;
+    if (k > K) return;
+    double a = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float g = dlogit_of(dout[n], out[n]);
+        a += (double)(k < K ? g * h[(int64_t)n * ldh + k] : g);
+    }
+    if (k < K) dw[k] = (float)a;
+    else db[0] = (float)a;
+}
+
+// loss = 1/n^2 sum_i sum_j (p_i - y_j)^2 = mean_i (p_i^2 - 2 p_i ybar + mean(y^2)); dpred_i = 2/n (p_i - ybar)
+__global__ __launch_bounds__(256) void mse_bcast_kernel(const float* __restrict__ pred, const float* __restrict__ labels, int N,
+                                                       float* __restrict__ loss, float* __restrict__ dpred) {
+    __shared__ double red[3][4];
+    __shared__ double ybar_s;
+    double sy = 0.0, sy2 = 0.0, sp = 0.0, sp2 = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double y = labels[i], p = pred[i];
+        sy += y; sy2 += y * y; sp += p; sp2 += p * p;
+    }
+    sy = wave_sum_d(sy); sy2 = wave_sum_d(sy2); sp = wave_sum_d(sp); sp2 = wave_sum_d(sp2);
+    __shared__ double r4[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        r4[wv][0] = sy; r4[wv][1] = sy2; r4[wv][2] = sp; r4[wv][3] = sp2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4];
+        for (int j = 0; j < 4; ++j) t[j] = r4[0][j] + r4[1][j] + r4[2][j] + r4[3][j];
+        const double n = (double)N;
+        const double ybar = t[0] / n;
+        ybar_s = ybar;
+        if (loss) loss[0] = (float)(t[3] / n - 2.0 * (t[2] / n) * ybar + t[1] / n);
+    }
+    __syncthreads();
+    (void)red;
+    if (dpred) {
+        const double ybar = ybar_s;
+        for (int i = threadIdx.x; i < N; i += 256) dpred[i] = (float)(2.0 / (double)N * ((double)pred[i] - ybar));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, single-tensor operation order), one pass over the flat arena.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float omb1, float omb2,
+                                      float eps, float step_size, float bc2_sqrt, float gs) {
+    g *= gs;
+    m = m + omb1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + (omb2 * g) * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);           // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, float b1, float b2, float omb1,
+                                                  float omb2, float eps, float step_size, float bc2_sqrt, float gs) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        adam1(p[i], g[i], m[i], v[i], b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+    }
+}
+
+unsigned grid1d(int64_t n, int cap = 4096) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu, float* y,
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream) {
+    GN_REQUIRE(x && w && b && y, GOALNET_E_NULL, "conv1d_fwd: null pointer");
+    GN_REQUIRE(N > 0 && Cin > 0 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE, "conv1d_fwd: bad dims");
+    const int Lo = (L + 2 * pad - 3) / stride + 1;
+    hipLaunchKernelGGL(conv1d_fwd_kernel, dim3(grid1d((int64_t)N * Cout * Lo)), dim3(256), 0, (hipStream_t)stream, x, w, b, relu, y,
+                       N, Cin, L, Cout, Lo, stride, pad);
+    GN_LAUNCH_CHECK("conv1d_fwd");
+    return 0;
+}
+
+int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* dx, float* dw, float* db,
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream) {
+    GN_REQUIRE(x && dz && w && dw && db, GOALNET_E_NULL, "conv1d_bwd: null pointer");
+    GN_REQUIRE(N > 0 && Cin > 0 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE, "conv1d_bwd: bad dims");
+    const int Lo = (L + 2 * pad - 3) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
+        GN_LAUNCH_CHECK("conv1d_bwd.dx");
+    }
+    hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
+    GN_LAUNCH_CHECK("conv1d_bwd.dw");
+    hipLaunchKernelGGL(conv1d_db_kernel, dim3(Cout), dim3(256), 0, st, dz, db, N, Cout, Lo);
+    GN_LAUNCH_CHECK("conv1d_bwd.db");
+    return 0;
+}
+
+int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
+    GN_REQUIRE(dy && y && dz, GOALNET_E_NULL, "relu_bwd: null pointer");
+    GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "relu_bwd: bad count");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dz, n);
+    GN_LAUNCH_CHECK("relu_bwd");
+    return 0;
+}
+
+int goalnet_mul(const float* x, int64_t ldx, const float* mult, int64_t ldmult, float* y, int64_t ldy,
+                int M, int J, void* stream) {
+    GN_REQUIRE(x && mult && y, GOALNET_E_NULL, "mul: null pointer");
+    GN_REQUIRE(M > 0 && J > 0, GOALNET_E_SHAPE, "mul: bad dims");
+    hipLaunchKernelGGL(mul_kernel, dim3(grid1d((int64_t)M * J)), dim3(256), 0, (hipStream_t)stream, x, ldx, mult, ldmult, y, ldy, M, J);
+    GN_LAUNCH_CHECK("mul");
+    return 0;
+}
+
+int goalnet_colsum(const float* x, int64_t ldx, int M, int J, float* out, void* stream) {
+    GN_REQUIRE(x && out, GOALNET_E_NULL, "colsum: null pointer");
+    GN_REQUIRE(M > 0 && J > 0, GOALNET_E_SHAPE, "colsum: bad dims");
+    hipLaunchKernelGGL(colsum_kernel, dim3((J + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, ldx, M, J, out);
+    GN_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+int goalnet_head_fwd(const float* h, int64_t ldh, const float* w, const float* b, float* logit, float* out,
+                     int N, int K, void* stream) {
+    GN_REQUIRE(h && w && b && out, GOALNET_E_NULL, "head_fwd: null pointer");
+    GN_REQUIRE(N > 0 && K > 0, GOALNET_E_SHAPE, "head_fwd: bad dims");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, ldh, w, b, logit, out, N, K);
+    GN_LAUNCH_CHECK("head_fwd");
+    return 0;
+}
+
+int goalnet_head_bwd(const float* dout, const float* out, const float* h, int64_t ldh, const float* w,
+                     const float* mult, int64_t ldmult, float* dh, int64_t lddh, float* dw, float* db,
+                     int N, int K, void* stream) {
+    GN_REQUIRE(dout && out && h && w && dh && dw && db, GOALNET_E_NULL, "head_bwd: null pointer");
+    GN_REQUIRE(N > 0 && K > 0 && K < 1024, GOALNET_E_SHAPE, "head_bwd: bad dims (K < 1024)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_bwd_dh_kernel, dim3(grid1d((int64_t)N * K)), dim3(256), 0, st, dout, out, w, mult, ldmult, dh, lddh, N, K);
+    GN_LAUNCH_CHECK("head_bwd.dh");
+    const int threads = ((K + 1 + 63) / 64) * 64;
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(1), dim3(threads), 0, st, dout, out, h, ldh, dw, db, N, K);
+    GN_LAUNCH_CHECK("head_bwd.dw");
+    return 0;
+}
+
+int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss, float* dpred, void* stream) {
+    GN_REQUIRE(pred && labels, GOALNET_E_NULL, "mse_bcast: null pointer");
+    GN_REQUIRE(N > 0, GOALNET_E_SHAPE, "mse_bcast: bad count");
+    hipLaunchKernelGGL(mse_bcast_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, labels, N, loss, dpred);
+    GN_LAUNCH_CHECK("mse_bcast");
+    return 0;
+}
+
+int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                      double beta2, double eps, int step, float grad_scale, void* stream) {
+    GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "adam_step: null pointer");
+    GN_REQUIRE(n > 0 && step >= 1, GOALNET_E_SHAPE, "adam_step: bad count or step");
+    GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "adam_step: arenas must be 16-byte aligned");
+    // host-side scalars exactly as torch's _single_tensor_adam computes them (python floats = doubles)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)beta1,
+                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, grad_scale);
+    GN_LAUNCH_CHECK("adam_step");
+    return 0;
+}
+
+}  // extern "C"

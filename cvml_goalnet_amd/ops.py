@@ -1,0 +1,264 @@
+"""Thin torch-tensor wrappers over the C ABI (include/goalnet_hip.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and
+torch.distributed. Every arithmetic operation of the hot path runs in libgoalnet_hip.so.
+Tensors are fp32, on the GPU, in the device layouts named in the header (NHWC / OHWI).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import STAT_PARTS, check
+
+F32 = torch.float32
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.GoalnetError("expected a GPU tensor")
+        if t.dtype not in (F32, torch.float64, torch.uint8):
+            raise _lib.GoalnetError(f"unexpected dtype {t.dtype}")
+
+
+def _ld(t):
+    """leading dimension (row stride) of a 2-D view with unit column stride"""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    return t.stride(0)
+
+
+def lib():
+    return _lib.load()
+
+
+# ---------------------------------------------------------------------------------------------
+def fill_uniform(dst, seed, tensor_id, lo, hi):
+    _chk(dst)
+    assert dst.is_contiguous() and dst.dtype == F32
+    check(lib().goalnet_fill_uniform(dst.data_ptr(), dst.numel(), seed, tensor_id, lo, hi, _s()), "fill_uniform")
+    return dst
+
+
+def dropout_mask(dst, seed, tensor_id, p):
+    _chk(dst)
+    assert dst.is_contiguous() and dst.dtype == F32
+    check(lib().goalnet_dropout_mask(dst.data_ptr(), dst.numel(), seed, tensor_id, p, _s()), "dropout_mask")
+    return dst
+
+
+def transpose_inner(src, dst, B, R, C):
+    """[B][R][C] -> [B][C][R] on contiguous buffers"""
+    _chk(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() == B * R * C
+    check(lib().goalnet_transpose_inner(src.data_ptr(), dst.data_ptr(), B, R, C, _s()), "transpose_inner")
+    return dst
+
+
+def conv3x3_weight_flip(w, wt, cout, cin):
+    _chk(w, wt)
+    assert w.numel() == wt.numel() == cout * cin * 9
+    check(lib().goalnet_conv3x3_weight_flip(w.data_ptr(), wt.data_ptr(), cout, cin, _s()), "conv3x3_weight_flip")
+    return wt
+
+
+def conv1_fwd(x_nchw, w, b, y, N, H, W):
+    _chk(x_nchw, w, b, y)
+    assert x_nchw.is_contiguous() and x_nchw.numel() == N * 3 * H * W
+    Ho, Wo = (H + 3) // 3 + 1, (W + 3) // 3 + 1
+    assert y.numel() == N * Ho * Wo * 64 and w.numel() == 64 * 27 and b.numel() == 64
+    check(lib().goalnet_conv1_fwd(x_nchw.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, _s()), "conv1_fwd")
+    return y
+
+
+def conv1_wgrad(x_nchw, dy, dw, db, N, H, W):
+    _chk(x_nchw, dy, dw, db)
+    Ho, Wo = (H + 3) // 3 + 1, (W + 3) // 3 + 1
+    assert dy.numel() == N * Ho * Wo * 64 and dw.numel() == 64 * 27 and db.numel() == 64
+    nbytes = lib().goalnet_conv1_wgrad_ws_bytes(N, H, W)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=dy.device)
+    check(lib().goalnet_conv1_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes,
+                                    N, H, W, _s()), "conv1_wgrad")
+
+
+def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
+    _chk(y, p, idx, partials)
+    assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
+    assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
+    assert partials.dtype == torch.float64 and partials.numel() >= STAT_PARTS * 2 * C
+    check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), N, Hc, Wc, C, _s()),
+          "pool_bnstats_fwd")
+
+
+def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mean, invstd, scale, shift):
+    _chk(partials, gamma, beta, rmean, rvar, mean, invstd, scale, shift)
+    for t in (gamma, beta, mean, invstd, scale, shift):
+        assert t.numel() == C and t.is_contiguous()
+    check(lib().goalnet_bn_finalize(partials.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps,
+                                    count, C, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _s()),
+          "bn_finalize")
+
+
+def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
+    _chk(dz, p, mean, invstd, partials)
+    assert dz.numel() == p.numel() == npix * C and partials.numel() >= STAT_PARTS * 2 * C
+    check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), npix, C,
+                                      _s()), "bn_bwd_reduce")
+
+
+def bn_bwd_finalize(partials, gamma, mean, invstd, count, C, dgamma, dbeta, coef3):
+    _chk(partials, gamma, mean, invstd, dgamma, dbeta, coef3)
+    assert coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C
+    check(lib().goalnet_bn_bwd_finalize(partials.data_ptr(), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), count, C,
+                                        dgamma.data_ptr(), dbeta.data_ptr(), coef3.data_ptr(), _s()), "bn_bwd_finalize")
+
+
+def bnpool_bwd(dz, p, idx, y, coef3, dy, dbias_partials, N, Hc, Wc, C):
+    _chk(dz, p, idx, y, coef3, dy, dbias_partials)
+    npool = N * (Hc - 2) * (Wc - 2) * C
+    assert dz.numel() == p.numel() == idx.numel() == npool and y.numel() == dy.numel() == N * Hc * Wc * C
+    assert dbias_partials.dtype == torch.float64 and dbias_partials.numel() >= STAT_PARTS * C
+    check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
+                                   dbias_partials.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd")
+
+
+def partials_sum(partials, nparts, stride, C, out):
+    _chk(partials, out)
+    assert partials.dtype == torch.float64 and out.numel() == C
+    check(lib().goalnet_partials_sum(partials.data_ptr(), nparts, stride, C, out.data_ptr(), _s()), "partials_sum")
+
+
+def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
+    _chk(x, scale, shift, w, bias, y)
+    assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    assert scale is None or (scale.numel() == Cin and shift.numel() == Cin)
+    assert bias is None or bias.numel() == Cout
+    check(lib().goalnet_conv3x3_fwd(x.data_ptr(), _p(scale), _p(shift), w.data_ptr(), _p(bias), int(relu), y.data_ptr(),
+                                    N, H, W, Cin, Cout, _s()), "conv3x3_fwd")
+    return y
+
+
+def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
+    _chk(x, scale, shift, dy, dw)
+    assert x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin
+    nbytes = lib().goalnet_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=x.device)
+    check(lib().goalnet_conv3x3_wgrad(x.data_ptr(), _p(scale), _p(shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+                                      N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
+    return dw
+
+
+def linear_fwd(x, w, bias, y, *, relu=False, scale=None, shift=None, bnC=0, dropmask=None, mult_out=None, K=None):
+    """y (M,J view) = act(x (M,K view) @ w(J,K)^T + bias) * dropmask. x/y/dropmask/mult_out may be column
+    slices of wider buffers (row stride = leading dim)."""
+    _chk(x, w, bias, y, scale, shift, dropmask, mult_out)
+    M = x.shape[0]
+    K = x.shape[1] if K is None else K
+    J = y.shape[1]
+    assert w.numel() == J * K and y.shape[0] == M
+    nbytes = lib().goalnet_linear_fwd_ws_bytes(M, K, J)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=x.device) if nbytes else None
+    check(lib().goalnet_linear_fwd(x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, w.data_ptr(), _p(bias), int(relu),
+                                   _p(dropmask), 0 if dropmask is None else _ld(dropmask), y.data_ptr(), _ld(y),
+                                   _p(mult_out), 0 if mult_out is None else _ld(mult_out), M, K, J, _p(ws), nbytes, _s()),
+          "linear_fwd")
+    return y
+
+
+def linear_bwd_dx(dy, w, dx, mult=None):
+    _chk(dy, w, dx, mult)
+    M, J = dy.shape
+    K = dx.shape[1]
+    assert w.numel() == J * K and dx.shape[0] == M
+    check(lib().goalnet_linear_bwd_dx(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
+                                      dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx")
+    return dx
+
+
+def linear_bwd_dw(dy, x, dw, *, scale=None, shift=None, bnC=0):
+    _chk(dy, x, dw, scale, shift)
+    M, J = dy.shape
+    K = x.shape[1]
+    assert dw.numel() == J * K and x.shape[0] == M
+    check(lib().goalnet_linear_bwd_dw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, dw.data_ptr(),
+                                      M, K, J, _s()), "linear_bwd_dw")
+    return dw
+
+
+def colsum(x, out):
+    _chk(x, out)
+    M, J = x.shape
+    assert out.numel() == J
+    check(lib().goalnet_colsum(x.data_ptr(), _ld(x), M, J, out.data_ptr(), _s()), "colsum")
+    return out
+
+
+def mul(x, m, y):
+    _chk(x, m, y)
+    M, J = x.shape
+    check(lib().goalnet_mul(x.data_ptr(), _ld(x), m.data_ptr(), _ld(m), y.data_ptr(), _ld(y), M, J, _s()), "mul")
+    return y
+
+
+def conv1d_fwd(x, w, b, y, relu, N, Cin, L, Cout, stride=2, pad=1):
+    _chk(x, w, b, y)
+    Lo = (L + 2 * pad - 3) // stride + 1
+    assert x.numel() == N * Cin * L and y.numel() == N * Cout * Lo and w.numel() == Cout * Cin * 3
+    check(lib().goalnet_conv1d_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), int(relu), y.data_ptr(), N, Cin, L, Cout, stride, pad,
+                                   _s()), "conv1d_fwd")
+    return y
+
+
+def conv1d_bwd(x, dz, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
+    _chk(x, dz, w, dx, dw, db)
+    Lo = (L + 2 * pad - 3) // stride + 1
+    assert x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo
+    check(lib().goalnet_conv1d_bwd(x.data_ptr(), dz.data_ptr(), w.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), N, Cin, L, Cout,
+                                   stride, pad, _s()), "conv1d_bwd")
+
+
+def relu_bwd(dy, y, dz):
+    _chk(dy, y, dz)
+    assert dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel()
+    check(lib().goalnet_relu_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _s()), "relu_bwd")
+    return dz
+
+
+def head_fwd(h, w, b, logit, out):
+    _chk(h, w, b, logit, out)
+    N, K = h.shape
+    check(lib().goalnet_head_fwd(h.data_ptr(), _ld(h), w.data_ptr(), b.data_ptr(), _p(logit), out.data_ptr(), N, K, _s()), "head_fwd")
+
+
+def head_bwd(dout, out, h, w, mult, dh, dw, db):
+    _chk(dout, out, h, w, mult, dh, dw, db)
+    N, K = h.shape
+    assert dout.numel() == N and out.numel() == N and dout.is_contiguous() and out.is_contiguous()
+    check(lib().goalnet_head_bwd(dout.data_ptr(), out.data_ptr(), h.data_ptr(), _ld(h), w.data_ptr(), _p(mult),
+                                 0 if mult is None else _ld(mult), dh.data_ptr(), _ld(dh), dw.data_ptr(), db.data_ptr(), N, K, _s()),
+          "head_bwd")
+
+
+def mse_bcast(pred, labels, loss, dpred):
+    _chk(pred, labels, loss, dpred)
+    N = pred.numel()
+    assert labels.numel() == N
+    check(lib().goalnet_mse_bcast(pred.data_ptr(), labels.data_ptr(), N, _p(loss), _p(dpred), _s()), "mse_bcast")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _chk(p, g, m, v)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    check(lib().goalnet_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, step, grad_scale,
+                                  _s()), "adam_step")

@@ -1,0 +1,157 @@
+/*
+ * goalnet_hip.h — C ABI of libgoalnet_hip.so: the MI355X (gfx950) kernels behind the reference's
+ * `AVM` hot path (forward, MSE, backward, Adam).
+ *
+ * The reference (Vasilispapg/CVML-GoalNet) has NO FFI, plugin or operator interface: its hot path
+ * is a Python class that bottoms out in PyTorch's ATen CPU kernels. Each entry
+ * point below therefore names the reference LINES whose arithmetic it replaces; the Python mirror of
+ * the reference interface (cvml_goalnet_amd/avm.py: `AVM(audio_included)`, `model(audio, visual)`,
+ * `state_dict`) is what a reference script binds, and it reaches these functions through ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions (fixed by SURVEY.md §8(b), last row):
+ *   - every function returns int: 0 = OK, negative = argument/shape error (GOALNET_E_*),
+ *     positive = hipError_t of the failed launch; goalnet_last_error() gives the text;
+ *   - never throws, never allocates or frees device memory, never synchronises the stream, holds no
+ *     global mutable state except the thread-local error string;
+ *   - all tensors are caller-allocated fp32 device buffers passed as raw pointers + explicit dims;
+ *     `stream` is a hipStream_t passed as void*;
+ *   - activations are NHWC ([N][H][W][C], C contiguous); conv weights are OHWI ([Cout][3][3][Cin]);
+ *     linear weights are [out][in] row-major; linear5's input dimension is in NHWC-flatten order
+ *     (h*W+w)*C + c (the Python layer permutes to/from the reference's NCHW-flatten order);
+ *   - 64-bit element counts wherever N*H*W*C can exceed 2^31.
+ */
+#ifndef GOALNET_HIP_H
+#define GOALNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOALNET_ABI_VERSION 1
+
+#define GOALNET_OK 0
+#define GOALNET_E_NULL (-1)      /* required pointer is NULL */
+#define GOALNET_E_SHAPE (-2)     /* dimension out of the supported set */
+#define GOALNET_E_ALIGN (-3)     /* pointer or leading dimension not 16-byte aligned */
+#define GOALNET_E_WORKSPACE (-4) /* workspace too small */
+
+/* number of per-block partial rows produced by the statistics kernels (fixed => deterministic sums) */
+#define GOALNET_STAT_PARTS 1024
+
+int goalnet_abi_version(void);
+const char* goalnet_last_error(void);
+
+/* ---- synthetic data (cvml_goalnet_amd/synth.py formula; bench/test inputs only) --------------- */
+int goalnet_fill_uniform(float* dst, int64_t n, uint64_t seed, uint32_t tensor_id, float lo, float hi, void* stream);
+/* dropout multipliers: 0 or 1/(1-p), keep iff u >= p.  Replaces nn.Dropout's Bernoulli draw,
+ * /root/reference/utils.py:170, 245-254 (torch's CPU RNG stream cannot be reproduced on device). */
+int goalnet_dropout_mask(float* dst, int64_t n, uint64_t seed, uint32_t tensor_id, float p, void* stream);
+
+/* ---- layout converters (state_dict interchange) --------------------------- */
+/* [B][R][C] -> [B][C][R]: OIHW<->OHWI (B=O,R=I,C=9 and back), NCHW<->NHWC, linear5 column order. */
+int goalnet_transpose_inner(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream);
+/* dgrad weights: wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] */
+int goalnet_conv3x3_weight_flip(const float* w_ohwi, float* wt, int Cout, int Cin, void* stream);
+
+/* ---- VisBl block 1: conv1 (3->64, k3 s3 p3) + bias + ReLU.  utils.py:151-152, 174-175 ---------- */
+int goalnet_conv1_fwd(const float* x_nchw, const float* w_ohwi, const float* bias, float* y_nhwc,
+                      int N, int H, int W, void* stream);
+/* dW (OHWI) and dbias of conv1 from dy = grad wrt its pre-ReLU output (NHWC). autograd of utils.py:174 */
+size_t goalnet_conv1_wgrad_ws_bytes(int N, int H, int W);
+int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohwi, float* dbias,
+                        void* ws, size_t ws_bytes, int N, int H, int W, void* stream);
+
+/* ---- MaxPool2d(3,1,0) + train-mode BatchNorm statistics.  utils.py:153-154 (and 158-159, 163-164) */
+/* p = maxpool3x3s1(y); idx = argmax position 0..8 (first max in kh,kw scan order, as ATen);
+ * partials[GOALNET_STAT_PARTS][2][C] (double) = per-block sum and sum of squares of p. */
+int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials,
+                             int N, int Hc, int Wc, int C, void* stream);
+/* mean/biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated
+ * with `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
+int goalnet_bn_finalize(const double* partials, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int64_t count,
+                        int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* BatchNorm backward, phase 1: per-channel sum(dz) and sum(dz * xhat) -> partials (double). */
+int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
+                          double* partials, int64_t npix, int C, void* stream);
+/* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
+int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const float* mean, const float* invstd,
+                            int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
+/* phase 3, fused: BN backward apply -> max-pool backward (gather by argmax) -> ReLU backward.
+ * dy[N][Hc][Wc][C] = grad wrt the conv's pre-ReLU output; dbias_partials (double
+ * [GOALNET_STAT_PARTS][C]) = per-block column sums of dy. */
+int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+                       float* dy, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream);
+/* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
+int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
+
+/* ---- VisBl blocks 2,3: conv 3x3 s1 p1 as implicit GEMM on fp32 MFMA.  utils.py:156-157, 161-162 --- */
+/* y = [relu](conv(bnapply(x), w) + bias).  scale/shift (per input channel) may be NULL (no BN on load);
+ * zero padding is applied AFTER the affine, as the reference pads the BatchNorm output. bias may be
+ * NULL. Also computes the data gradient when called with goalnet_conv3x3_weight_flip'ed weights. */
+int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, const float* w_ohwi,
+                        const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+/* dw[Cout][3][3][Cin] = sum_m dy[m][co] * bnapply(x)[m + tap][ci]; split over m, deterministic. */
+size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
+                          void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- Linear layers (linear5, audbl.linear3, fusion.0/3/6/9).  utils.py:168-170, 211, 243-253 ---- */
+/* y[m][j] = act(sum_k xa[m][k] * w[j][k] + bias[j]) * dropmask[m][j]
+ *   xa = x*scale[k % bnC] + shift[k % bnC] when scale != NULL (BatchNorm folded into the load);
+ *   relu != 0 applies ReLU; dropmask may be NULL; mult_out (nullable) receives
+ *   (pre-activation > 0 ? 1 : 0) * dropmask, the multiplier the backward pass needs.
+ * Split-K with a deterministic slab reduction is used when the grid would not fill the chip. */
+size_t goalnet_linear_fwd_ws_bytes(int M, int64_t K, int J);
+int goalnet_linear_fwd(const float* x, int64_t ldx, const float* scale, const float* shift, int bnC,
+                       const float* w, const float* bias, int relu, const float* dropmask, int64_t ldmask,
+                       float* y, int64_t ldy, float* mult_out, int64_t ldmult,
+                       int M, int64_t K, int J, void* ws, size_t ws_bytes, void* stream);
+/* dx[m][k] = (sum_j dy[m][j] * w[j][k]) * mult[m][k]   (mult nullable) */
+int goalnet_linear_bwd_dx(const float* dy, int64_t lddy, const float* w, const float* mult, int64_t ldmult,
+                          float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
+/* dw[j][k] = sum_m dy[m][j] * xa[m][k]   (xa as in goalnet_linear_fwd) */
+int goalnet_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx,
+                          const float* scale, const float* shift, int bnC,
+                          float* dw, int M, int64_t K, int J, void* stream);
+/* out[j] = sum_m x[m][j] (deterministic) — bias gradients */
+int goalnet_colsum(const float* x, int64_t ldx, int M, int J, float* out, void* stream);
+/* y = x * mult (elementwise over [M][J] with leading dims) */
+int goalnet_mul(const float* x, int64_t ldx, const float* mult, int64_t ldmult, float* y, int64_t ldy,
+                int M, int J, void* stream);
+
+/* ---- AudBl convolutions.  utils.py:203-207, 216-220 -------------------------------------------- */
+/* y[n][co][lo] = [relu](b[co] + sum_{ci,k} x[n][ci][stride*lo - pad + k] * w[co][ci][k]), k = 3 */
+int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu, float* y,
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream);
+/* dz = grad wrt pre-activation. dx nullable (first layer needs none). */
+int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* dx, float* dw, float* db,
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream);
+/* dz = dy * (y > 0) */
+int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream);
+
+/* ---- head: fusion.12 (128 -> 1), Sigmoid, 4*y + 1.  utils.py:255-256, 270 ----------------------- */
+int goalnet_head_fwd(const float* h, int64_t ldh, const float* w, const float* b, float* logit, float* out,
+                     int N, int K, void* stream);
+/* dout[N] -> dh = dlogit * w * mult (nullable), dw, db.  dlogit = dout * (out-1) * (5-out) / 4 */
+int goalnet_head_bwd(const float* dout, const float* out, const float* h, int64_t ldh, const float* w,
+                     const float* mult, int64_t ldmult, float* dh, int64_t lddh, float* dw, float* db,
+                     int N, int K, void* stream);
+
+/* ---- loss: nn.MSELoss()(pred(n,1), labels(n,)) with its (n,n) broadcast.  main.py:68, 191 -------- */
+/* loss = 1/n^2 sum_i sum_j (p_i - y_j)^2 ; dpred_i = 2/n * (p_i - mean(y)) (nullable) */
+int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss, float* dpred, void* stream);
+
+/* ---- optimizer: torch.optim.Adam defaults over a flat arena.  main.py:70, 193 ------------------- */
+/* g is scaled by grad_scale first (1/world_size after a SUM all-reduce). `step` is 1-based. */
+int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                      double beta2, double eps, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOALNET_HIP_H */

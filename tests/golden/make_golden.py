@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE ITSELF (build container only).
+
+Imports `/root/reference/utils.py` as the oracle of record with the recipe of SURVEY.md Appendix B
+(the I/O libraries it imports at module top — cv2, librosa, h5py, moviepy — are absent from the image
+and unused by the hot path, so empty module objects are registered for them before the import; no
+reference source is edited or copied), drives `utils.AVM` exactly as `/root/reference/main.py:187-193`
+does, and
+
+  1. proves the CPU restatement `oracle/avm_ref.py` equal to it (bit-equal where ATen allows, else
+     within the tolerance printed), and
+  2. writes small fixtures (full small tensors; {sum, sum of squares, abs-max, 16 samples} for
+     large ones) as tests/golden/*.npz. Weights / inputs / dropout masks are NOT stored: they are
+     regenerated from cvml_goalnet_amd/synth.py's seed formula on both sides.
+
+Nothing here runs on the GPU box; /root/reference does not exist there.
+Usage:  python tests/golden/make_golden.py [--only NAME_SUBSTR]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+import warnings
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from cvml_goalnet_amd import synth  # noqa: E402
+from oracle import avm_ref  # noqa: E402
+
+FULL_LIMIT = 4096  # tensors up to this many elements are stored whole
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    for name in ("cv2", "librosa", "h5py", "moviepy", "moviepy.editor"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["moviepy.editor"].VideoFileClip = object
+    import utils  # the reference
+    return utils
+
+
+class MaskMul(torch.nn.Module):
+    """Stands in for an nn.Dropout instance ON THE ORACLE INSTANCE so that the mask is a known input
+    (x * m with m in {0, 1/(1-p)} is exactly what F.dropout computes for its own Bernoulli draw)."""
+
+    def __init__(self):
+        super().__init__()
+        self.mask = None
+
+    def forward(self, x):
+        return x * self.mask
+
+
+def salt_of(name: str) -> int:
+    return zlib.crc32(name.encode()) & 0xFFFF
+
+
+def summarize(name: str, t: torch.Tensor, out: dict):
+    a = t.detach().to(torch.float64).reshape(-1).numpy()
+    if a.size <= FULL_LIMIT:
+        out[name + "|full"] = t.detach().reshape(-1).numpy().copy()
+    else:
+        idx = synth.sample_indices(a.size, 16, salt_of(name))
+        out[name + "|stats"] = np.array([a.sum(), (a * a).sum(), np.abs(a).max()], dtype=np.float64)
+        out[name + "|samples"] = t.detach().reshape(-1).numpy()[idx].copy()
+    out[name + "|shape"] = np.array(t.shape, dtype=np.int64)
+
+
+def build_inputs(n, h, audio_included, bins=30):
+    vis = torch.from_numpy(synth.make_visual(n, h, h))
+    aud = torch.from_numpy(synth.make_audio(n, bins)) if audio_included else [None] * n
+    lab = torch.from_numpy(synth.make_labels(n))
+    return aud, vis, lab
+
+
+def _reference_steps(utils, n, h, audio_included, drop, steps, params_np, aud, vis, lab, keep_tensors):
+    """Drive the reference `utils.AVM` as main.py:187-193 does. Returns (fixture dict, per-step tensors)."""
+    ref = utils.AVM(audio_included=audio_included)
+    sd = {k: torch.from_numpy(v) for k, v in params_np.items()}
+    sd.update(avm_ref.init_buffers())
+    ref.load_state_dict(sd)                                   # main.py:66 (before any forward)
+    del sd
+    drops = ["visbl.drop5", "fusion.2", "fusion.5", "fusion.8", "fusion.11"]
+    maskmods = []
+    for dn in drops:
+        parent = ref.visbl if dn.startswith("visbl.") else ref.fusion
+        key = dn.split(".", 1)[1]
+        if drop == "p0":
+            (getattr(parent, key) if not key.isdigit() else parent[int(key)]).p = 0.0
+        else:
+            mm = MaskMul()
+            maskmods.append(mm)
+            if key.isdigit():
+                parent[int(key)] = mm
+            else:
+                setattr(parent, key, mm)
+    criterion = torch.nn.MSELoss()                            # main.py:68
+    optimizer = torch.optim.Adam(params=ref.parameters(), lr=0.001)  # main.py:70
+
+    acts = {}
+    hooks = []
+    want = {"visbl.relu1": ref.visbl.relu1, "visbl.maxpool1": ref.visbl.maxpool1, "visbl.bnorm1": ref.visbl.bnorm1,
+            "visbl.maxpool2": ref.visbl.maxpool2, "visbl.bnorm2": ref.visbl.bnorm2,
+            "visbl.maxpool3": ref.visbl.maxpool3, "visbl.bnorm3": ref.visbl.bnorm3,
+            "visbl.drop5": ref.visbl.drop5, "logit": ref.fusion[12]}
+    if audio_included:
+        want["audbl.relu3"] = ref.audbl.relu3
+    for an, mod in want.items():
+        hooks.append(mod.register_forward_hook(lambda m, i, o, an=an: acts.__setitem__(an, o.detach().clone())))
+
+    fx = {}
+    kept = []
+    for s in range(steps):
+        if drop == "mask":
+            masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, step=s)]
+            for mm, m in zip(maskmods, masks):
+                mm.mask = m
+        optimizer.zero_grad()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pred = ref(aud, vis)
+            loss = criterion(pred, lab)
+        loss.backward()
+        pre = f"s{s}."
+        summarize(pre + "pred", pred.detach(), fx)
+        summarize(pre + "loss", loss.detach().reshape(1), fx)
+        for k, v in acts.items():
+            summarize(pre + "act." + k, v, fx)
+        for k, v in ref.named_parameters():
+            summarize(pre + "grad." + k, v.grad, fx)
+        t = None
+        if keep_tensors:
+            t = {"pred": pred.detach().clone(), "loss": loss.detach().clone(),
+                 "grad": {k: v.grad.detach().clone() for k, v in ref.named_parameters()},
+                 "act": dict(acts)}
+        optimizer.step()
+        for k, v in ref.named_parameters():
+            summarize(pre + "param." + k, v.detach(), fx)
+        for k, v in ref.named_buffers():
+            summarize(pre + "buf." + k, v.detach().to(torch.float64) if v.dtype == torch.int64 else v.detach(), fx)
+        if keep_tensors:
+            t["param"] = {k: v.detach().clone() for k, v in ref.named_parameters()}
+            t["buf"] = {k: v.detach().clone() for k, v in ref.named_buffers()}
+            kept.append(t)
+    for hk in hooks:
+        hk.remove()
+    return fx, kept
+
+
+def run_case(utils, name, n, h, audio_included, drop, steps, out_dir):
+    print(f"== {name}: N={n} H=W={h} audio={audio_included} dropout={drop} steps={steps}", flush=True)
+    big = h > 100   # 1.29 G parameters: run reference and restatement one after the other, compare summaries
+    params_np = synth.make_params(h, h, 30, audio_included)
+    aud, vis, lab = build_inputs(n, h, audio_included)
+
+    fx, kept = _reference_steps(utils, n, h, audio_included, drop, steps, params_np, aud, vis, lab, not big)
+
+    # ---------------- restatement ----------------
+    p = {k: torch.from_numpy(v) for k, v in params_np.items()}
+    del params_np
+    b = avm_ref.init_buffers()
+    state = {}
+    equal_report = {}
+
+    def cmp(tag, x, y):
+        if x.numel() == 0 and y.numel() == 0:
+            equal_report[tag] = (True, 0.0, 0.0)
+            return
+        eq = torch.equal(x, y)
+        err = (x.double() - y.double()).abs().max().item()
+        rel = err / max(y.double().abs().max().item(), 1e-30)
+        equal_report[tag] = (eq, err, rel)
+
+    fo = {}
+    for s in range(steps):
+        masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, step=s)] if drop == "mask" else None
+        inter = {}
+        o_loss, o_pred, o_g = avm_ref.train_step(p, b, state, aud if audio_included else None, vis, lab,
+                                                 masks, audio_included, inter)
+        pre = f"s{s}."
+        if big:
+            summarize(pre + "pred", o_pred, fo)
+            summarize(pre + "loss", o_loss.reshape(1), fo)
+            for k in [a.split("act.", 1)[1].split("|")[0] for a in fx if a.startswith(pre + "act.") and a.endswith("|shape")]:
+                summarize(pre + "act." + k, inter[k], fo)
+            for k, v in o_g.items():
+                summarize(pre + "grad." + k, v, fo)
+            for k, v in p.items():
+                summarize(pre + "param." + k, v, fo)
+            for k, v in b.items():
+                summarize(pre + "buf." + k, v.to(torch.float64) if v.dtype == torch.int64 else v, fo)
+        else:
+            t = kept[s]
+            cmp(pre + "pred", o_pred, t["pred"])
+            cmp(pre + "loss", o_loss, t["loss"])
+            for k in t["grad"]:
+                cmp(pre + "grad." + k, o_g[k], t["grad"][k])
+            for k in t["param"]:
+                cmp(pre + "param." + k, p[k], t["param"][k])
+            for k in t["buf"]:
+                cmp(pre + "buf." + k, b[k], t["buf"][k])
+            for k in t["act"]:
+                cmp(pre + "act." + k, inter[k], t["act"][k])
+    if big:
+        assert set(fo.keys()) == set(fx.keys()), sorted(set(fo) ^ set(fx))[:8]
+        for k in fx:
+            x, y = torch.from_numpy(np.asarray(fo[k], dtype=np.float64)), torch.from_numpy(np.asarray(fx[k], dtype=np.float64))
+            cmp(k, x, y)
+
+    n_eq = sum(1 for v in equal_report.values() if v[0])
+    worst = max(equal_report.items(), key=lambda kv: kv[1][2])
+    print(f"   restatement vs reference ({'summaries' if big else 'full tensors'}): {n_eq}/{len(equal_report)} bit-equal; "
+          f"worst rel err {worst[1][2]:.3e} at {worst[0]} (abs {worst[1][1]:.3e})", flush=True)
+    bad = {k: v for k, v in equal_report.items() if v[2] > 1e-5}
+    if bad:
+        raise SystemExit(f"restatement disagrees with the reference: {bad}")
+    fx["meta|n"] = np.array([n]); fx["meta|h"] = np.array([h]); fx["meta|steps"] = np.array([steps])
+    fx["meta|audio"] = np.array([int(audio_included)]); fx["meta|drop"] = np.array([0 if drop == "p0" else 1])
+    fx["meta|bit_equal"] = np.array([n_eq, len(equal_report)])
+    fx["meta|worst_rel"] = np.array([worst[1][2]])
+    fx["meta|torch"] = np.array([ord(c) for c in torch.__version__], dtype=np.int64)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **fx)
+
+
+CASES = [
+    # name, N, H, audio, dropout, steps
+    ("avm_a1_n10_h40_p0", 10, 40, True, "p0", 1),
+    ("avm_a1_n10_h40_mask3", 10, 40, True, "mask", 3),
+    ("avm_a0_n10_h40_mask", 10, 40, False, "mask", 1),
+    ("avm_a1_n1_h40_p0", 1, 40, True, "p0", 1),
+    ("avm_a1_n16_h40_mask", 16, 40, True, "mask", 1),
+    ("avm_a0_n7_h52_p0", 7, 52, False, "p0", 1),
+    ("avm_a1_n2_h224_p0", 2, 224, True, "p0", 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    utils = import_reference()
+    for c in CASES:
+        if args.only and args.only not in c[0]:
+            continue
+        run_case(utils, *c, out_dir=HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,328 @@
+"""GPU: every C-ABI kernel against the CPU oracle ops (torch CPU, fp64) on seeded inputs, called through the
+C ABI (cvml_goalnet_amd.ops -> ctypes -> libgoalnet_hip.so). Tolerances are stated per test; integer/index
+results (argmax positions, generator bits, masks) are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cvml_goalnet_amd import ops, synth  # noqa: E402
+from oracle import avm_ref  # noqa: E402
+
+DEV = "cuda:0"
+RT = 2e-6   # fp32 kernels vs fp64 reference, relative to the tensor's max |value|
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * (hi - lo) + lo).float()
+
+
+def close(name, got, want, rtol=RT, atol=0.0):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item()
+    print(f"[parity] {name}: max|err| = {err:.3e}  scale = {scale:.3e}  rel = {err / scale:.3e}")
+    assert err <= rtol * scale + atol, f"{name}: err {err:.3e} > {rtol:.1e} * {scale:.3e}"
+
+
+def nhwc(t):   # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_fill_uniform_and_dropout_mask_bit_exact():
+    for tid, n, lo, hi in ((3, 1000, -0.5, 0.25), (77, 70001, 0.0, 1.0)):
+        d = torch.empty(n, device=DEV)
+        ops.fill_uniform(d, synth.BASE_SEED, tid, lo, hi)
+        want = synth.uniform(tid, (n,), lo, hi)
+        assert np.array_equal(d.cpu().numpy(), want)
+    for step in (0, 2):
+        masks = synth.make_drop_masks(9, step=step)
+        for li, m in enumerate(masks):
+            d = torch.empty(m.shape, device=DEV)
+            ops.dropout_mask(d, synth.BASE_SEED, synth.TID_DROP + 8 * step + li, synth.DROP_P)
+            assert np.array_equal(d.cpu().numpy(), m)
+
+
+def test_layout_converters_exact():
+    x = rnd(5, 37, 70, seed=1)
+    d = torch.empty(5 * 37 * 70, device=DEV)
+    ops.transpose_inner(x.to(DEV).view(-1), d, 5, 37, 70)
+    assert torch.equal(d.cpu().view(5, 70, 37), x.permute(0, 2, 1).contiguous())
+    w = rnd(8, 3, 3, 12, seed=2)      # OHWI
+    wt = torch.empty(w.numel(), device=DEV)
+    ops.conv3x3_weight_flip(w.to(DEV).view(-1), wt, 8, 12)
+    want = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()     # [ci][2-kh][2-kw][co]
+    assert torch.equal(wt.cpu().view(12, 3, 3, 8), want)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 40, 40), (3, 41, 38), (2, 7, 9)])
+def test_conv1_fwd_and_wgrad(n, h, w):
+    x = rnd(n, 3, h, w, seed=3, lo=0, hi=1)
+    wt = rnd(64, 3, 3, 3, seed=4, lo=-0.2, hi=0.2)       # OIHW
+    b = rnd(64, seed=5, lo=-0.2, hi=0.2)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=3, padding=3))
+    ho, wo = ref.shape[2], ref.shape[3]
+    y = torch.empty(n, ho, wo, 64, device=DEV)
+    w_ohwi = wt.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ops.conv1_fwd(x.to(DEV), w_ohwi, b.to(DEV), y, n, h, w)
+    close("conv1_fwd", y, nhwc(ref))
+    dy = rnd(n, ho, wo, 64, seed=6)
+    xd = x.double().requires_grad_(False)
+    wd = wt.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    out = F.conv2d(xd, wd, bd, stride=3, padding=3)
+    out.backward(nchw(dy).double())
+    dw = torch.empty(64, 3, 3, 3, device=DEV)
+    db = torch.empty(64, device=DEV)
+    ops.conv1_wgrad(x.to(DEV), dy.to(DEV), dw, db, n, h, w)
+    close("conv1_wgrad.dw", dw, wd.grad.permute(0, 2, 3, 1), rtol=2e-5)
+    close("conv1_wgrad.db", db, bd.grad, rtol=2e-5)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,affine,bias,relu", [
+    (2, 7, 5, 64, 256, True, True, True),       # M = 70 < one tile
+    (3, 13, 13, 64, 256, True, True, True),     # reference conv2 geometry (40x40 frames)
+    (2, 11, 11, 256, 512, True, True, True),    # reference conv3 geometry
+    (2, 11, 11, 512, 256, False, False, False), # data-gradient form of conv3
+    (2, 13, 13, 256, 64, False, False, False),  # data-gradient form of conv2 (N tile mostly empty)
+    (1, 3, 3, 64, 128, True, False, True),
+])
+def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
+    x = rnd(n, h, w, cin, seed=7)
+    sc = rnd(cin, seed=8, lo=0.5, hi=1.5) if affine else None
+    sh = rnd(cin, seed=9, lo=-0.5, hi=0.5) if affine else None
+    wt = rnd(cout, 3, 3, cin, seed=10, lo=-0.05, hi=0.05)
+    b = rnd(cout, seed=11) if bias else None
+    xn = x.double() * sc.double() + sh.double() if affine else x.double()
+    ref = F.conv2d(nchw(xn), wt.double().permute(0, 3, 1, 2), None if b is None else b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV)
+    ops.conv3x3_fwd(x.to(DEV), None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), wt.to(DEV),
+                    None if b is None else b.to(DEV), relu, y, n, h, w, cin, cout)
+    close(f"conv3x3_fwd[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref))
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,affine", [
+    (2, 7, 5, 64, 256, True),
+    (3, 13, 13, 64, 256, True),
+    (2, 11, 11, 256, 512, True),
+    (5, 9, 6, 64, 128, False),
+])
+def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
+    x = rnd(n, h, w, cin, seed=12)
+    sc = rnd(cin, seed=13, lo=0.5, hi=1.5) if affine else None
+    sh = rnd(cin, seed=14, lo=-0.5, hi=0.5) if affine else None
+    dy = rnd(n, h, w, cout, seed=15)
+    xn = x.double() * sc.double() + sh.double() if affine else x.double()
+    ref = torch.nn.grad.conv2d_weight(nchw(xn), (cout, cin, 3, 3), nchw(dy.double()), padding=1)
+    dw = torch.full((cout, 3, 3, cin), float("nan"), device=DEV)
+    ops.conv3x3_wgrad(x.to(DEV), None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), dy.to(DEV), dw,
+                      n, h, w, cin, cout)
+    close(f"conv3x3_wgrad[{n}x{h}x{w}x{cin}->{cout}]", dw, ref.permute(0, 2, 3, 1), rtol=5e-6)
+
+
+@pytest.mark.parametrize("n,hc,wc,c", [(2, 15, 15, 64), (3, 13, 13, 256), (1, 11, 11, 512), (2, 3, 5, 64)])
+def test_pool_bn_forward_and_backward(n, hc, wc, c):
+    z = rnd(n, hc, wc, c, seed=16)
+    y = F.relu(z)                                     # conv output after ReLU: many exact zeros (ties)
+    gamma = rnd(c, seed=17, lo=0.5, hi=1.5)
+    beta = rnd(c, seed=18, lo=-0.5, hi=0.5)
+    rm0 = rnd(c, seed=19)
+    rv0 = rnd(c, seed=20, lo=0.5, hi=2.0)
+    # ---- oracle (fp64 autograd): utils.py:175-177
+    zd = nchw(z.double()).requires_grad_(True)
+    yd = F.relu(zd)
+    pd, pidx = F.max_pool2d(yd, 3, 1, 0, return_indices=True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    od = F.batch_norm(pd, rm, rv, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    G = rnd(*od.shape, seed=21).double()
+    (od * G).sum().backward()
+    # ---- device
+    hp, wp = hc - 2, wc - 2
+    yg = y.to(DEV)
+    p = torch.empty(n, hp, wp, c, device=DEV)
+    idx = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=DEV)
+    partials = torch.empty(ops.STAT_PARTS * 2 * c, dtype=torch.float64, device=DEV)
+    ops.pool_bnstats_fwd(yg, p, idx, partials, n, hc, wc, c)
+    st = torch.empty(4, c, device=DEV)
+    rmg, rvg = rm0.to(DEV), rv0.to(DEV)
+    ops.bn_finalize(partials, gamma.to(DEV), beta.to(DEV), rmg, rvg, 0.1, 1e-5, n * hp * wp, c, st[0], st[1], st[2], st[3])
+    close("maxpool", p, nhwc(pd), rtol=0.0)
+    # argmax: torch flat index ih*Wc+iw -> tap (ih-ph)*3 + (iw-pw); first-max tie rule must agree (bit-exact)
+    ih = pidx // wc
+    iw = pidx % wc
+    ph = torch.arange(hp).view(1, 1, hp, 1)
+    pw = torch.arange(wp).view(1, 1, 1, wp)
+    tap = ((ih - ph) * 3 + (iw - pw)).to(torch.uint8)
+    assert torch.equal(idx.cpu(), nhwc(tap)), "argmax positions differ from ATen's"
+    mean = pd.mean(dim=(0, 2, 3))
+    var = pd.var(dim=(0, 2, 3), unbiased=False)
+    close("bn.mean", st[0], mean, rtol=1e-6)
+    close("bn.invstd", st[1], 1.0 / torch.sqrt(var + 1e-5), rtol=1e-6)
+    close("bn.running_mean", rmg, rm, rtol=1e-6)
+    close("bn.running_var", rvg, rv, rtol=1e-6)
+    bn_out = p * st[2] + st[3]
+    close("bn.apply(scale,shift)", bn_out, nhwc(od), rtol=2e-6)
+    # ---- backward chain
+    dbn = nhwc(G.float()).to(DEV)
+    ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, n * hp * wp, c)
+    coef3 = torch.empty(3 * c, device=DEV)
+    dgamma = torch.empty(c, device=DEV)
+    dbeta = torch.empty(c, device=DEV)
+    ops.bn_bwd_finalize(partials, gamma.to(DEV), st[0], st[1], n * hp * wp, c, dgamma, dbeta, coef3)
+    dy = torch.empty(n, hc, wc, c, device=DEV)
+    ops.bnpool_bwd(dbn, p, idx, yg, coef3, dy, partials, n, hc, wc, c)
+    dbias = torch.empty(c, device=DEV)
+    ops.partials_sum(partials, ops.STAT_PARTS, c, c, dbias)
+    close("bn.dgamma", dgamma, gd.grad, rtol=5e-6)
+    close("bn.dbeta", dbeta, bd.grad, rtol=5e-6)
+    close("block.dz (bn+pool+relu bwd)", dy, nhwc(zd.grad), rtol=1e-5)
+    close("block.dbias", dbias, zd.grad.sum(dim=(0, 2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,k,j,affine,mask,ldextra", [
+    (10, 41472, 512, True, True, 128),     # linear5 at the reference's sub-batch (split-K path)
+    (37, 640, 512, False, True, 0),        # fusion.0
+    (130, 512, 256, False, False, 0),      # ragged M over two tiles
+    (1, 1024, 128, False, False, 512),     # audbl.linear3, N = 1
+])
+def test_linear_fwd(m, k, j, affine, mask, ldextra):
+    x = rnd(m, k, seed=22)
+    w = rnd(j, k, seed=23, lo=-0.05, hi=0.05)
+    b = rnd(j, seed=24)
+    bnc = 512 if affine else 0
+    sc = rnd(512, seed=25, lo=0.5, hi=1.5) if affine else None
+    sh = rnd(512, seed=26, lo=-0.5, hi=0.5) if affine else None
+    dm = (torch.rand(m, j, generator=torch.Generator().manual_seed(27)) >= 0.2).float() * 1.25 if mask else None
+    xd = x.double()
+    if affine:
+        ch = torch.arange(k) % 512
+        xd = xd * sc.double()[ch] + sh.double()[ch]
+    pre = xd @ w.double().t() + b.double()
+    ref = F.relu(pre) * (dm.double() if mask else 1.0)
+    ybuf = torch.full((m, j + ldextra), float("nan"), device=DEV)
+    mbuf = torch.full((m, j + ldextra), float("nan"), device=DEV)
+    yv, mv = ybuf[:, ldextra:], mbuf[:, ldextra:]
+    ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), yv, relu=True, scale=None if sc is None else sc.to(DEV),
+                   shift=None if sh is None else sh.to(DEV), bnC=bnc, dropmask=None if dm is None else dm.to(DEV), mult_out=mv)
+    close(f"linear_fwd[{m}x{k}->{j}]", yv, ref, rtol=3e-6)
+    # mult = (pre > 0) * mask; pre-activations within fp32 noise of 0 may legitimately differ
+    want_mult = (pre > 0).double() * (dm.double() if mask else 1.0)
+    safe = pre.abs() > 1e-4
+    assert torch.equal(mv.cpu().double()[safe], want_mult[safe])
+    if ldextra:
+        assert torch.isnan(ybuf[:, :ldextra]).all(), "wrote outside the column slice"
+
+
+@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True), (1, 256, 128, True)])
+def test_linear_bwd_dx(m, k, j, use_mult):
+    dy = rnd(m, j, seed=28)
+    w = rnd(j, k, seed=29, lo=-0.05, hi=0.05)
+    mult = (torch.rand(m, k, generator=torch.Generator().manual_seed(30)) >= 0.5).float() * 1.25 if use_mult else None
+    ref = dy.double() @ w.double()
+    if use_mult:
+        ref = ref * mult.double()
+    dx = torch.full((m, k), float("nan"), device=DEV)
+    ops.linear_bwd_dx(dy.to(DEV), w.to(DEV), dx, mult=None if mult is None else mult.to(DEV))
+    close(f"linear_bwd_dx[{m}x{j}->{k}]", dx, ref, rtol=3e-6)
+
+
+@pytest.mark.parametrize("m,k,j,affine", [(10, 41472, 512, True), (37, 640, 512, False), (130, 512, 256, False), (1, 1024, 128, False)])
+def test_linear_bwd_dw(m, k, j, affine):
+    dy = rnd(m, j, seed=31)
+    x = rnd(m, k, seed=32)
+    sc = rnd(512, seed=33, lo=0.5, hi=1.5) if affine else None
+    sh = rnd(512, seed=34, lo=-0.5, hi=0.5) if affine else None
+    xd = x.double()
+    if affine:
+        ch = torch.arange(k) % 512
+        xd = xd * sc.double()[ch] + sh.double()[ch]
+    ref = dy.double().t() @ xd
+    dw = torch.full((j, k), float("nan"), device=DEV)
+    ops.linear_bwd_dw(dy.to(DEV), x.to(DEV), dw, scale=None if sc is None else sc.to(DEV), shift=None if sh is None else sh.to(DEV),
+                      bnC=512 if affine else 0)
+    close(f"linear_bwd_dw[{m}: {j}x{k}]", dw, ref, rtol=3e-6)
+    out = torch.empty(j, device=DEV)
+    ops.colsum(dy.to(DEV), out)
+    close("colsum", out, dy.double().sum(0), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,bins", [(1, 30), (10, 30), (33, 17)])
+def test_audbl_conv1d(n, bins):
+    x = rnd(n, 30, bins, seed=35, lo=-50, hi=50)
+    w1 = rnd(64, 30, 3, seed=36, lo=-0.1, hi=0.1); b1 = rnd(64, seed=37)
+    w2 = rnd(128, 64, 3, seed=38, lo=-0.07, hi=0.07); b2 = rnd(128, seed=39)
+    xd = x.double()
+    w1d, b1d, w2d, b2d = (t.double().requires_grad_(True) for t in (w1, b1, w2, b2))
+    a1 = F.relu(F.conv1d(xd, w1d, b1d, stride=2, padding=1))
+    a2 = F.relu(F.conv1d(a1, w2d, b2d, stride=2, padding=1))
+    G = rnd(*a2.shape, seed=40).double()
+    (a2 * G).sum().backward()
+    l1, l2 = a1.shape[2], a2.shape[2]
+    xg = x.to(DEV)
+    g1 = torch.empty(n, 64, l1, device=DEV); g2 = torch.empty(n, 128, l2, device=DEV)
+    ops.conv1d_fwd(xg, w1.to(DEV), b1.to(DEV), g1, True, n, 30, bins, 64)
+    ops.conv1d_fwd(g1, w2.to(DEV), b2.to(DEV), g2, True, n, 64, l1, 128)
+    close("audbl.conv1", g1, a1, rtol=3e-6); close("audbl.conv2", g2, a2, rtol=3e-6)
+    dz2 = torch.empty_like(g2)
+    ops.relu_bwd(G.float().to(DEV), g2, dz2)
+    da1 = torch.empty_like(g1); dw2 = torch.empty(128, 64, 3, device=DEV); db2 = torch.empty(128, device=DEV)
+    ops.conv1d_bwd(g1, dz2, w2.to(DEV), da1, dw2, db2, n, 64, l1, 128)
+    ops.relu_bwd(da1, g1, da1)
+    dw1 = torch.empty(64, 30, 3, device=DEV); db1 = torch.empty(64, device=DEV)
+    ops.conv1d_bwd(xg, da1, w1.to(DEV), None, dw1, db1, n, 30, bins, 64)
+    close("audbl.dw2", dw2, w2d.grad, rtol=1e-5); close("audbl.db2", db2, b2d.grad, rtol=1e-5)
+    close("audbl.dw1", dw1, w1d.grad, rtol=1e-5); close("audbl.db1", db1, b1d.grad, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 10, 300])
+def test_head_and_mse(n):
+    h = rnd(n, 128, seed=41)
+    w = rnd(128, seed=42, lo=-0.1, hi=0.1)
+    b = rnd(1, seed=43)
+    lab = torch.from_numpy(synth.make_labels(n))
+    mult = (torch.rand(n, 128, generator=torch.Generator().manual_seed(44)) >= 0.2).float() * 1.25
+    hd = h.double().requires_grad_(True); wd = w.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    z = hd @ wd + bd
+    out = 4 * torch.sigmoid(z) + 1
+    loss = avm_ref.mse_bcast(out.view(n, 1), lab.double())
+    loss.backward()
+    logit = torch.empty(n, device=DEV); og = torch.empty(n, device=DEV)
+    ops.head_fwd(h.to(DEV), w.to(DEV), b.to(DEV), logit, og)
+    close("head.logit", logit, z, rtol=2e-6); close("head.out", og, out, rtol=1e-6)
+    lg = torch.empty(1, device=DEV); dpred = torch.empty(n, device=DEV)
+    ops.mse_bcast(og, lab.to(DEV), lg, dpred)
+    close("mse_bcast.loss", lg, loss.detach().view(1), rtol=2e-6)
+    dh = torch.empty(n, 128, device=DEV); dw = torch.empty(128, device=DEV); db = torch.empty(1, device=DEV)
+    ops.head_bwd(dpred, og, h.to(DEV), w.to(DEV), mult.to(DEV), dh, dw, db)
+    close("head.dh", dh, hd.grad * mult.double(), rtol=5e-6)
+    close("head.dw", dw, wd.grad, rtol=5e-6); close("head.db", db, bd.grad.view(1), rtol=5e-6)
+
+
+def test_adam_three_steps_matches_torch_adam():
+    n = 100003
+    p0 = rnd(n, seed=45)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_ref], lr=1e-3)
+    pg = p0.to(DEV).clone(); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    # 16-byte aligned arenas, odd length exercises the tail
+    for step in range(1, 4):
+        g = rnd(n, seed=45 + step, lo=-1e-2, hi=1e-2)
+        g[::7] = 0.0
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(pg, g.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
+        close(f"adam.step{step}", pg, p_ref.detach(), rtol=0.0, atol=2e-7)
