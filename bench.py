@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — training clips/s of the AVM hot path on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input: forward, broadcast-MSE, backward and the
+fused Adam of `AVM` (/root/reference/main.py:187-193) on 64 clips x 16 frames = 1024 frames of 3x224x224 (+ a
+30x30 MFCC each) per GPU — the configuration BASELINE.json's metric is quoted on. Inputs are resident in HBM
+before the timed region. N > 1 is weak scaling: every rank trains its own 64 clips (local BatchNorm, local
+MSE, as an independent reference process would), gradients are summed over RCCL/xGMI in three buckets
+overlapped with backward and averaged inside the fused Adam (cvml_goalnet_amd/ddp.py).
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel = the fp32-MFMA implicit-GEMM convolution forward (conv2 + conv3, 84 % of
+                forward MACs): algorithmic flops of its launches / their duration, measured with HIP events
+                inside the timed steps; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (CPU restatement of the reference, oracle/avm_ref.py) timed on this host's cores on a
+                bounded sample (1 clip = 16 frames of 224x224 per step), rank 0, N = 1 only.
+  parity        logit MAE / max-abs of the HIP forward vs that CPU reference on the same 16 frames and weights.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+FRAMES_PER_CLIP = 16
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(n, h, w, device, seed):
+    from cvml_goalnet_amd import ops, synth
+    vis = torch.empty(n, 3, h, w, device=device)
+    ops.fill_uniform(vis.view(-1), seed, synth.TID_VISUAL, 0.0, 1.0)
+    flat = vis.view(n, -1)
+    mn = flat.amin(dim=1, keepdim=True)
+    mx = flat.amax(dim=1, keepdim=True)
+    flat.sub_(mn).div_(mx - mn)                      # per-frame min-max to [0,1], as utils.py:284 (data prep, untimed)
+    aud = torch.from_numpy(synth.make_audio(n, 30, seed)).to(device)
+    lab = torch.from_numpy(synth.make_labels(n, seed)).to(device)
+    return aud, vis, lab
+
+
+def cpu_baseline_and_parity(model, h, w, seed, max_seconds=40.0):
+    """Time the oracle's train step on the host cores (bounded sample) and compare logits on the same inputs."""
+    from cvml_goalnet_amd import synth
+    from oracle import avm_ref
+    n = FRAMES_PER_CLIP
+    threads = torch.get_num_threads()
+    sd = model.state_dict()                                          # torch-native layouts, CPU
+    p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    b = {k: v.clone() for k, v in sd.items() if k not in p}
+    aud, vis, lab = make_inputs(n, h, w, model._device, seed + 1)
+    a_c, v_c, l_c = aud.cpu(), vis.cpu(), lab.cpu()
+    # parity: forward with dropout masks regenerated from the seed formula on both sides
+    step = model._drop_step
+    masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, seed=model.dropout_seed, step=step)]
+    bn_backup = {k: getattr(*model._module_of(k)).clone() for k in b}
+    with torch.no_grad():
+        model.forward_device(aud, vis, save=False)
+    hip_logit = model.last_logit.cpu()
+    for k, v in bn_backup.items():                                   # the parity probe must not disturb the model
+        getattr(*model._module_of(k)).copy_(v)
+    inter = {}
+    with torch.no_grad():
+        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, a_c, v_c, masks, model.audio_included, inter)
+    ref_logit = inter["logit"].view(-1)
+    mae = (hip_logit - ref_logit).abs().mean().item()
+    mx = (hip_logit - ref_logit).abs().max().item()
+    # timing: train steps of one clip (the Adam state allocation of the first step is the warm-up)
+    state = {}
+    times = []
+    t_begin = time.time()
+    for i in range(3):
+        t0 = time.time()
+        avm_ref.train_step(p, b, state, a_c, v_c, l_c, masks, model.audio_included)
+        times.append(time.time() - t0)
+        if time.time() - t_begin > max_seconds:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    base = {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"oracle train step (fwd+MSE+bwd+Adam) on {n} frames (1 clip) of {h}x{w}, fp32, torch {torch.__version__} CPU, "
+                      f"{len(times)} steps, best of the non-first: {t:.2f} s/step"}
+    par = {"logit_mae_vs_cpu_ref": mae, "logit_maxabs_vs_cpu_ref": mx, "frames": n, "dropout": "masks from seed formula", "bn": "train"}
+    return base, par
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=64, help="clips of 16 frames per GPU per step")
+    ap.add_argument("--hw", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-audio", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    dev = torch.device("cuda", local)
+
+    from cvml_goalnet_amd import AVM, synth
+    from cvml_goalnet_amd.ddp import GradSync
+
+    n = args.clips * FRAMES_PER_CLIP
+    h = w = args.hw
+    seed = synth.BASE_SEED + rank
+    torch.manual_seed(1234)                                   # same initial weights on every rank
+    model = AVM(audio_included=not args.no_audio, device=dev, seed=seed)
+    aud, vis, lab = make_inputs(n, h, w, dev, seed)
+    if args.no_audio:
+        aud = None
+    if world > 1:
+        model.grad_sync = GradSync()
+
+    for _ in range(args.warmup):
+        model.train_step(aud, vis, lab)
+    model.kernel_events = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, pred = model.train_step(aud, vis, lab)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    events = model.kernel_events
+    model.kernel_events = None
+    assert torch.isfinite(loss).all() and torch.isfinite(pred).all(), "non-finite loss/prediction"
+
+    if rank == 0:
+        clips = args.clips * world * args.steps
+        res = {
+            "metric": "training clips/sec at batch 64, 16-frame 224² clips; logit MAE vs CPU ref",
+            "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"AVM train step (forward + broadcast-MSE + backward + fused Adam), {args.clips} clips x 16 frames = "
+                                   f"{n} frames of 3x{h}x{w} + 30x30 MFCC per GPU; dropout live (device masks), BatchNorm train mode",
+                       "frames_per_gpu": n, "h": h, "w": w, "global_clips_per_step": args.clips * world,
+                       "parallelism": f"dp{world}", "ddp_semantics": "local BN + local MSE per rank, gradient mean (standard DDP)",
+                       "params": int(sum(s.numel for s in model._specs)), "final_loss": float(loss.item())},
+        }
+        ev = events.get("conv_fwd", [])
+        if ev:
+            ms = [a.elapsed_time(b) for a, b, _ in ev]
+            fl = [f for _, _, f in ev]
+            achieved = sum(fl) / (sum(ms) * 1e-3) / 1e12
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "conv_fwd_traffic.json")
+            if os.path.exists(tj) and args.clips == 64 and h == 224:
+                try:
+                    traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "kernel": "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)",
+                               "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms),
+                               "algorithmic_flops_per_launch": sum(fl) / len(fl)}
+            others = {}
+            for k, lst in events.items():
+                if k == "conv_fwd":
+                    continue
+                t = sum(a.elapsed_time(b) for a, b, _ in lst) * 1e-3
+                others[k] = {"tflops": sum(f for _, _, f in lst) / t / 1e12, "ms_per_step": 1e3 * t / args.steps}
+            res["other_kernels"] = others
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                base, par = cpu_baseline_and_parity(model, h, w, synth.BASE_SEED)
+                res["cpu_baseline"] = base
+                res["parity"] = par
+            except Exception as e:  # the bench line must still be printed
+                log(f"cpu_baseline failed: {e!r}")
+                res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

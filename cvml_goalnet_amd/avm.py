@@ -104,8 +104,10 @@ class AVM(nn.Module):
         self._hw3 = self._l2 = None
         self._adam_t = 0
         self._materialized = False
-        self.grad_sync = None          # optional callable(model) run between backward and Adam (ddp.py)
+        self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
+        self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
+        self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
     # ------------------------------------------------------------------------------------------
     # parameter arena
@@ -315,6 +317,18 @@ class AVM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # forward / backward on device tensors
     # ------------------------------------------------------------------------------------------
+    def _timed(self, label, flops, fn, *args):
+        """Run one kernel launch; when bench.py asked for it, bracket it with HIP events on the launching stream."""
+        if self.kernel_events is None:
+            return fn(*args)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args)
+        e1.record()
+        self.kernel_events.setdefault(label, []).append((e0, e1, flops))
+        return r
+
     @staticmethod
     def _sizes(h, w):
         h1, w1 = (h + 3) // 3 + 1, (w + 3) // 3 + 1
@@ -361,10 +375,12 @@ class AVM(nn.Module):
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
         y2 = torch.empty(n, hp1, wp1, 256, dtype=F32, device=dev)
-        ops.conv3x3_fwd(p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+        self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
+                    p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
         y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
-        ops.conv3x3_fwd(p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+        self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
+                    p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
         p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save)
 
         fw = 640 if self.audio_included else 512
@@ -475,22 +491,26 @@ class AVM(nn.Module):
         dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
         del dbn3
         st2 = ctx["st2"]
-        ops.conv3x3_wgrad(ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+        self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
+                    ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         dbn2 = torch.empty(n, hp2, wp2, 256, dtype=F32, device=dev)
-        ops.conv3x3_fwd(dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
+        self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
+                    dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
         del dy3
 
         # block 2 (utils.py:179-182)
         dy2 = self._block_bwd(dbn2, ctx, 2, n, hp1, wp1, 256)
         del dbn2
         st1 = ctx["st1"]
-        ops.conv3x3_wgrad(ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+        self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
+                    ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
         wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
-        ops.conv3x3_fwd(dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
+        self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
+                    dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
         del dy2
 
         # block 1 (utils.py:174-177); conv1's input needs no gradient
@@ -544,6 +564,7 @@ class AVM(nn.Module):
         dout = torch.empty(n, dtype=F32, device=self._device)
         ops.mse_bcast(out, labels, loss, dout)
         sync = self.grad_sync
+        self.last_ctx = ctx if self.keep_ctx else None
         self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)
         scale = 1.0
         if sync is not None:

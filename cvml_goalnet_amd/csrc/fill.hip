@@ -22,8 +22,11 @@ __device__ __forceinline__ float unit24(uint64_t key, int64_t i) {
 }
 
 __global__ __launch_bounds__(256) void fill_uniform_kernel(float* dst, int64_t n, uint64_t key, float lo, float span) {
+    // numpy rounds the product, then the sum. hipcc's default -ffp-contract=fast would fuse `lo + span * u` into one
+    // fma (and __fmul_rn/__fadd_rn are plain operators in HIP); fma(span, u, 0) is the rounded product and cannot
+    // be contracted with the following add.
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = __fadd_rn(lo, __fmul_rn(span, unit24(key, i)));   // two roundings, as numpy does (no FMA)
+        dst[i] = lo + __builtin_fmaf(span, unit24(key, i), 0.0f);
 }
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* dst, int64_t n, uint64_t key, float p, float scale) {

@@ -49,14 +49,55 @@ def init_buffers(dtype=torch.float32) -> Dict[str, torch.Tensor]:
     return b
 
 
-def _vis_block(x, p, b, i, stride, pad, inter):
+class _ForcedMaxPool(torch.autograd.Function):
+    """MaxPool2d(3, 1) whose argmax positions are GIVEN (taps 0..8 = kh*3+kw inside each window).
+
+    Max-pool routing is discontinuous: when the two largest values of a window are 1 ulp apart, two correct
+    fp32 implementations of the preceding convolution can pick different positions, and every gradient upstream
+    then differs at O(1) in a few elements. Parity tests therefore compare backward passes under the SAME routing
+    decisions (the device's), and check separately that every disagreement with the natural argmax is such a
+    near-tie (tests/test_gpu_avm.py)."""
+
+    @staticmethod
+    def forward(ctx, x, taps):
+        n, c, h, w = x.shape
+        hp, wp = h - 2, w - 2
+        t = taps.long()
+        flat = (torch.arange(hp).view(1, 1, hp, 1) + t // 3) * w + (torch.arange(wp).view(1, 1, 1, wp) + t % 3)
+        ctx.save_for_backward(flat)
+        ctx.shape = x.shape
+        return x.reshape(n, c, h * w).gather(2, flat.reshape(n, c, -1)).reshape(n, c, hp, wp)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        gi = torch.zeros(n, c, h * w, dtype=g.dtype).scatter_add_(2, flat.reshape(n, c, -1), g.reshape(n, c, -1))
+        return gi.reshape(n, c, h, w), None
+
+
+def natural_taps(y: torch.Tensor):
+    """ATen's own argmax of MaxPool2d(3,1) on y (N,C,H,W) as taps 0..8, plus the gap between the largest and the
+    second largest value of every window."""
+    pooled, pidx = F.max_pool2d(y, 3, 1, 0, return_indices=True)
+    w = y.shape[3]
+    hp, wp = pooled.shape[2], pooled.shape[3]
+    ih, iw = pidx // w, pidx % w
+    taps = ((ih - torch.arange(hp).view(1, 1, hp, 1)) * 3 + (iw - torch.arange(wp).view(1, 1, 1, wp))).to(torch.uint8)
+    u = F.unfold(y.reshape(-1, 1, y.shape[2], y.shape[3]), 3).transpose(1, 2)
+    top2 = u.topk(2, dim=2).values
+    gap = (top2[..., 0] - top2[..., 1]).reshape(pooled.shape)
+    return taps, gap, pooled
+
+
+def _vis_block(x, p, b, i, stride, pad, inter, taps=None):
     """conv -> ReLU -> MaxPool(3,1) -> train-mode BatchNorm  (utils.py:174-187)."""
     pre = f"visbl.conv{i}"
     x = F.conv2d(x, p[pre + ".weight"], p[pre + ".bias"], stride=stride, padding=pad)
     x = F.relu(x)
     if inter is not None:
         inter[f"visbl.relu{i}"] = x
-    x = F.max_pool2d(x, kernel_size=3, stride=1, padding=0)
+    x = F.max_pool2d(x, kernel_size=3, stride=1, padding=0) if taps is None else _ForcedMaxPool.apply(x, taps)
     if inter is not None:
         inter[f"visbl.maxpool{i}"] = x
     bn = f"visbl.bnorm{i}"
@@ -70,22 +111,25 @@ def _vis_block(x, p, b, i, stride, pad, inter):
 
 def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visual,
             drop_masks: Optional[List[torch.Tensor]] = None, audio_included: bool = True,
-            inter: Optional[dict] = None) -> torch.Tensor:
+            inter: Optional[dict] = None, pool_taps: Optional[dict] = None) -> torch.Tensor:
     """AVM.forward(audio_input, visual_input) -> (N,1) in (1,5).  utils.py:260-272.
 
     `b` (BN running stats) is updated in place, as the reference's train-mode forward does even under
     no_grad. `drop_masks`: [visbl.drop5, fusion.2, fusion.5, fusion.8, fusion.11] multipliers or None.
     `inter`: optional dict that receives named intermediate activations.
+    `pool_taps`: optional {1,2,3 -> uint8 (N,C,Hp,Wp)} argmax positions to force in the three max-pools
+    (tests only, see _ForcedMaxPool); None = the reference's own behaviour.
     """
+    pt = pool_taps or {}
     dm = drop_masks if drop_masks is not None else [None] * 5
 
     def drop(x, m):
         return x if m is None else x * m
 
     # VisBl, utils.py:172-195
-    x = _vis_block(visual, p, b, 1, 3, 3, inter)
-    x = _vis_block(x, p, b, 2, 1, 1, inter)
-    x = _vis_block(x, p, b, 3, 1, 1, inter)
+    x = _vis_block(visual, p, b, 1, 3, 3, inter, pt.get(1))
+    x = _vis_block(x, p, b, 2, 1, 1, inter, pt.get(2))
+    x = _vis_block(x, p, b, 3, 1, 1, inter, pt.get(3))
     x = torch.flatten(x, 1)                                   # NCHW flatten: c*H*W + h*W + w
     x = F.relu(F.linear(x, p["visbl.linear5.weight"], p["visbl.linear5.bias"]))
     v = drop(x, dm[0])
@@ -144,10 +188,10 @@ def adam_step(p: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor], state: dic
         w.addcdiv_(m, denom, value=-step_size)
 
 
-def train_step(p, b, state, audio, visual, labels, drop_masks=None, audio_included=True, inter=None):
+def train_step(p, b, state, audio, visual, labels, drop_masks=None, audio_included=True, inter=None, pool_taps=None):
     """One sub-batch train step, main.py:187-193. Returns (loss, pred, grads). `p` is updated in place."""
     leaf = {k: v.detach().requires_grad_(True) for k, v in p.items()}
-    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter)
+    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter, pool_taps)
     loss = mse_bcast(pred, labels)
     names = list(leaf.keys())
     grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)

@@ -10,7 +10,7 @@ does, and
   1. proves the CPU restatement `oracle/avm_ref.py` equal to it (bit-equal where ATen allows, else
      within the tolerance printed), and
   2. writes small fixtures (full small tensors; {sum, sum of squares, abs-max, 16 samples} for
-     large ones) as tests/golden/*.npz. Weights / inputs / dropout masks are NOT stored: they are
+     large ones; 64 samples at indices shared by a parameter's gradient and value) as tests/golden/*.npz. Weights / inputs / dropout masks are NOT stored: they are
      regenerated from cvml_goalnet_amd/synth.py's seed formula on both sides.
 
 Nothing here runs on the GPU box; /root/reference does not exist there.
@@ -60,8 +60,14 @@ class MaskMul(torch.nn.Module):
         return x * self.mask
 
 
+NSAMPLES = 64
+
+
 def salt_of(name: str) -> int:
-    return zlib.crc32(name.encode()) & 0xFFFF
+    """Sampling salt from the tensor's BASE name (step and grad./param./act./buf. prefixes stripped), so the
+    gradient and the updated value of a parameter are sampled at the same indices in every step."""
+    base = name.split(".", 2)[2] if name[0] == "s" and name[1].isdigit() else name
+    return zlib.crc32(base.encode()) & 0xFFFF
 
 
 def summarize(name: str, t: torch.Tensor, out: dict):
@@ -69,7 +75,7 @@ def summarize(name: str, t: torch.Tensor, out: dict):
     if a.size <= FULL_LIMIT:
         out[name + "|full"] = t.detach().reshape(-1).numpy().copy()
     else:
-        idx = synth.sample_indices(a.size, 16, salt_of(name))
+        idx = synth.sample_indices(a.size, NSAMPLES, salt_of(name))
         out[name + "|stats"] = np.array([a.sum(), (a * a).sum(), np.abs(a).max()], dtype=np.float64)
         out[name + "|samples"] = t.detach().reshape(-1).numpy()[idx].copy()
     out[name + "|shape"] = np.array(t.shape, dtype=np.int64)

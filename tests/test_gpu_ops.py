@@ -95,6 +95,8 @@ def test_conv1_fwd_and_wgrad(n, h, w):
     (2, 11, 11, 256, 512, True, True, True),    # reference conv3 geometry
     (2, 11, 11, 512, 256, False, False, False), # data-gradient form of conv3
     (2, 13, 13, 256, 64, False, False, False),  # data-gradient form of conv2 (N tile mostly empty)
+    (16, 11, 11, 512, 256, False, False, False),# M = 1936: 16 M-tiles, ragged last tile
+    (16, 11, 11, 256, 512, True, True, True),
     (1, 3, 3, 64, 128, True, False, True),
 ])
 def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
@@ -110,7 +112,7 @@ def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
     y = torch.full((n, h, w, cout), float("nan"), device=DEV)
     ops.conv3x3_fwd(x.to(DEV), None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), wt.to(DEV),
                     None if b is None else b.to(DEV), relu, y, n, h, w, cin, cout)
-    close(f"conv3x3_fwd[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref))
+    close(f"conv3x3_fwd[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)   # K up to 4608 fp32 accumulations
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,affine", [
@@ -118,6 +120,9 @@ def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
     (3, 13, 13, 64, 256, True),
     (2, 11, 11, 256, 512, True),
     (5, 9, 6, 64, 128, False),
+    (16, 11, 11, 256, 512, True),     # M = 1936 -> 3 splits over the reduction
+    (16, 13, 13, 64, 256, True),      # M = 2704 -> 5 splits, 576 columns (4.5 N-tiles)
+    (40, 13, 13, 64, 256, False),
 ])
 def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
     x = rnd(n, h, w, cin, seed=12)
@@ -132,7 +137,7 @@ def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
     close(f"conv3x3_wgrad[{n}x{h}x{w}x{cin}->{cout}]", dw, ref.permute(0, 2, 3, 1), rtol=5e-6)
 
 
-@pytest.mark.parametrize("n,hc,wc,c", [(2, 15, 15, 64), (3, 13, 13, 256), (1, 11, 11, 512), (2, 3, 5, 64)])
+@pytest.mark.parametrize("n,hc,wc,c", [(2, 15, 15, 64), (3, 13, 13, 256), (1, 11, 11, 512), (2, 3, 5, 64), (16, 11, 11, 512), (20, 13, 13, 256)])
 def test_pool_bn_forward_and_backward(n, hc, wc, c):
     z = rnd(n, hc, wc, c, seed=16)
     y = F.relu(z)                                     # conv output after ReLU: many exact zeros (ties)
@@ -190,7 +195,9 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c):
     close("bn.dgamma", dgamma, gd.grad, rtol=5e-6)
     close("bn.dbeta", dbeta, bd.grad, rtol=5e-6)
     close("block.dz (bn+pool+relu bwd)", dy, nhwc(zd.grad), rtol=1e-5)
-    close("block.dbias", dbias, zd.grad.sum(dim=(0, 2, 3)), rtol=1e-5)
+    # sum(dz) cancels (BatchNorm backward sums to ~0 per channel): tolerance relative to |dz| * sqrt(count)
+    close("block.dbias", dbias, zd.grad.sum(dim=(0, 2, 3)), rtol=0.0,
+          atol=3e-6 * zd.grad.abs().max().item() * (n * hc * wc) ** 0.5)
 
 
 @pytest.mark.parametrize("m,k,j,affine,mask,ldextra", [
@@ -302,7 +309,7 @@ def test_head_and_mse(n):
     loss.backward()
     logit = torch.empty(n, device=DEV); og = torch.empty(n, device=DEV)
     ops.head_fwd(h.to(DEV), w.to(DEV), b.to(DEV), logit, og)
-    close("head.logit", logit, z, rtol=2e-6); close("head.out", og, out, rtol=1e-6)
+    close("head.logit", logit, z, rtol=2e-6, atol=2e-7); close("head.out", og, out, rtol=1e-6)
     lg = torch.empty(1, device=DEV); dpred = torch.empty(n, device=DEV)
     ops.mse_bcast(og, lab.to(DEV), lg, dpred)
     close("mse_bcast.loss", lg, loss.detach().view(1), rtol=2e-6)
