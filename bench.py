@@ -117,8 +117,10 @@ def main():
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     import torch.distributed as dist
-    if world > 1:
+    distributed = world > 1 or os.environ.get("GOALNET_DDP_FORCE") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
@@ -137,23 +139,23 @@ def main():
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if args.no_audio:
         aud = None
-    if world > 1:
+    if distributed:
         model.grad_sync = GradSync()
 
     for _ in range(args.warmup):
         model.train_step(aud, vis, lab)
     model.kernel_events = {}
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, pred = model.train_step(aud, vis, lab)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -207,7 +209,7 @@ def main():
                 log(f"cpu_baseline failed: {e!r}")
                 res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -132,6 +132,58 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     if (kg == 0) row[CO * KP + co] = accb;
 }
 
+// v2: one output ROW (n, oh) per iteration. The 9 input row segments (3 channels x 3 kernel rows) a whole output row
+// needs are contiguous in the NCHW frame and are staged coalesced; v1 gathered 27 scattered scalars per pixel with
+// 64-bit divisions and ran at 12.7 ms for 20 GFLOP.
+__global__ __launch_bounds__(256) void conv1_wgrad_v2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partial, int N, int H, int W, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int XW = 3 * Wo;
+    float* xs = sm;                 // [9][XW]   row r = ci*3 + kh, element j <-> iw = j - 3
+    float* dys = sm + 9 * XW;       // [Wo][64]
+    const int tid = threadIdx.x;
+    const int co = tid & 63, kg = tid >> 6;
+    int off[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 7 * kg + j < KP ? 7 * kg + j : 0;
+        const int ci = k % 3, t = k / 3, kh = t / 3, kw = t - 3 * kh;
+        off[j] = (ci * 3 + kh) * XW + kw;
+    }
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    const int nrows = N * Ho;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / Ho, oh = row - n * Ho;
+        __syncthreads();
+        for (int i = tid; i < 9 * XW; i += 256) {
+            const int r = i / XW, j = i - r * XW;
+            const int ci = r / 3, kh = r - 3 * ci;
+            const int ih = 3 * oh - 3 + kh, iw = j - 3;
+            float v = 0.f;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[(((int64_t)n * 3 + ci) * H + ih) * W + iw];
+            xs[i] = v;
+        }
+        const float4* src = reinterpret_cast<const float4*>(dy + (int64_t)row * Wo * CO);
+        for (int i = tid; i < Wo * (CO / 4); i += 256) reinterpret_cast<float4*>(dys)[i] = src[i];
+        __syncthreads();
+        for (int ow = 0; ow < Wo; ++ow) {
+            const float d = dys[ow * CO + co];
+            accb += d;
+            const float* xp = xs + 3 * ow;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = fmaf(d, xp[off[j]], acc[j]);
+        }
+    }
+    float* prow = partial + (int64_t)blockIdx.x * (CO * KP + CO);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 7 * kg + j;
+        if (k < KP) prow[co * KP + k] = acc[j];
+    }
+    if (kg == 0) prow[CO * KP + co] = accb;
+}
+
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                 float* __restrict__ dw, float* __restrict__ db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -172,8 +224,13 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
     GN_REQUIRE(N > 0 && H > 0 && W > 0, GOALNET_E_SHAPE, "conv1_wgrad: non-positive dim");
     GN_REQUIRE(ws_bytes >= goalnet_conv1_wgrad_ws_bytes(N, H, W), GOALNET_E_WORKSPACE, "conv1_wgrad: workspace too small");
     const int Ho = (H + 3) / 3 + 1, Wo = (W + 3) / 3 + 1;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(WG_PARTS), dim3(256), 0, (hipStream_t)stream, x_nchw, dy_nhwc,
-                       (float*)ws, N, H, W, Ho, Wo);
+    const size_t lds = (size_t)(9 * 3 * Wo + Wo * CO) * sizeof(float);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(conv1_wgrad_v2_kernel, dim3(WG_PARTS), dim3(256), lds, (hipStream_t)stream, x_nchw, dy_nhwc,
+                           (float*)ws, N, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(WG_PARTS), dim3(256), 0, (hipStream_t)stream, x_nchw, dy_nhwc,
+                           (float*)ws, N, H, W, Ho, Wo);
     GN_LAUNCH_CHECK("conv1_wgrad");
     hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((CO * KP + CO + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, WG_PARTS, dw_ohwi, dbias);

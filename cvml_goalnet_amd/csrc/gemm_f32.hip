@@ -18,6 +18,8 @@
 // The K order inside a K-tile is permuted identically for A and B (lane half h of MFMA step j of group s
 // holds k = 8s + 4h + j) so that a K-contiguous operand is read from LDS with one ds_read_b128 per four
 // MFMA steps; rows are padded to 36 floats, which makes those reads bank-conflict free.
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace goalnet;
@@ -295,33 +297,64 @@ __device__ __forceinline__ void read_frag(const float* l, int rowbase, int s, in
 }
 
 template <bool AKC, bool BKC>
-__device__ __forceinline__ void compute_tile(const float* la, const float* lb, f32x16 (&acc)[2][2],
-                                             int wm, int wn, int r, int h) {
+__device__ __forceinline__ void read_group(const float* la, const float* lb, int wm, int wn, int s, int r, int h,
+                                           float (&a)[2][4], float (&b)[2][4]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float a[2][4], b[2][4];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            read_frag<AKC>(la, wm * 64 + f * 32, s, r, h, a[f]);
-            read_frag<BKC>(lb, wn * 64 + f * 32, s, r, h, b[f]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < 2; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm][j], b[fn][j], acc[fm][fn], 0, 0, 0);
-        }
+    for (int f = 0; f < 2; ++f) {
+        read_frag<AKC>(la, wm * 64 + f * 32, s, r, h, a[f]);
+        read_frag<BKC>(lb, wn * 64 + f * 32, s, r, h, b[f]);
     }
 }
 
-template <class AL, class BL>
+__device__ __forceinline__ void mfma_group(const float (&a)[2][4], const float (&b)[2][4], f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm][j], b[fn][j], acc[fm][fn], 0, 0, 0);
+    }
+}
+
+// One K-tile = 4 groups of 16 MFMAs. VAR 0: fragments are read right before their group (hipcc sinks the reads to
+// the end of the previous group, exposing ~100 cycles of LDS latency per group). VAR 1: software-pipelined — the
+// fragments of group s+1 are in flight while group s runs on the matrix pipe (two fragment register sets).
+template <bool AKC, bool BKC, int VAR>
+__device__ __forceinline__ void compute_tile(const float* la, const float* lb, f32x16 (&acc)[2][2],
+                                             int wm, int wn, int r, int h) {
+    if (VAR == 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float a[2][4], b[2][4];
+            read_group<AKC, BKC>(la, lb, wm, wn, s, r, h, a, b);
+            mfma_group(a, b, acc);
+        }
+    } else {
+        float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+        read_group<AKC, BKC>(la, lb, wm, wn, 0, r, h, a0, b0);
+        read_group<AKC, BKC>(la, lb, wm, wn, 1, r, h, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        read_group<AKC, BKC>(la, lb, wm, wn, 2, r, h, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a1, b1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        read_group<AKC, BKC>(la, lb, wm, wn, 3, r, h, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(a0, b0, acc);
+        mfma_group(a1, b1, acc);
+    }
+}
+
+template <class AL, class BL, int VAR>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[VAR == 8 ? 4 : 2][2][OP_FLOATS];   // VAR 8: 1 block/CU experiment
     const int tid = threadIdx.x;
+    if (VAR == 8 && ktiles < 0) lds[3][1][tid] = 0.f;
     const unsigned v = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
     int tm, tn;
     if (m_fast) { tm = (int)(v % (unsigned)tiles_m); tn = (int)(v / (unsigned)tiles_m); }
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles, kt0 + ktiles_per_split);
 
-    AL al(ap, tm * BM, tid);
+    AL al(ap, VAR == 2 ? 0 : tm * BM, tid);      // VAR 2: timing experiment, every block reads M-tile 0 (L2-resident)
     BL bl(bp, tn * BN, tid);
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -355,21 +388,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
         store_tile<BL::KC>(lds[0][1], rb, tid);
     }
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            al.issue(kt + 1, ra);
-            bl.issue(kt + 1, rb);
-        }
-        compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
-        if (more) {
+    if (VAR == 7) {
+        // One basic block per K-tile (staging is unconditional: the last iteration re-stages the final tile into the
+        // spare buffer), so that the scheduler can follow the interleave below: every fp32 MFMA occupies the matrix
+        // pipe for 64 cycles, during which the SAME wave can issue the address arithmetic, global loads, LDS reads,
+        // affine and LDS writes of the staging — instead of running them as a separate phase in front of the MFMAs.
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            const int nxt = kt + 1 < kt1 ? kt + 1 : kt;
+            al.issue(nxt, ra);
+            bl.issue(nxt, rb);
+            compute_tile<AL::KC, BL::KC, 0>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
             al.finish(ra);
             bl.finish(rb);
             store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
             store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
+            // ---- interleave: masks 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+            __builtin_amdgcn_sched_group_barrier(0x100, AL::KC && BL::KC ? 4 : 8, 0);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 40) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                if (i % 16 == 8 && i < 48) __builtin_amdgcn_sched_group_barrier(0x100, AL::KC && BL::KC ? 4 : 8, 0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = (VAR == 3 || VAR == 4) ? false : kt + 1 < kt1;   // VAR 3/4: timing experiments (no staging)
+        if (more) {
+            if (VAR != 9) al.issue(kt + 1, ra);       // VAR 9: B loads only; VAR 10: A loads only (timing experiments)
+            if (VAR != 10) bl.issue(kt + 1, rb);
+        }
+        compute_tile<AL::KC, BL::KC, (VAR == 1 ? 1 : 0)>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        if (more) {
+            if (VAR == 5 || VAR == 9 || VAR == 10) {          // timing experiment: loads only, no finish / LDS write
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+                    asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+                }
+            } else if (VAR == 6) {   // timing experiment: loads + LDS write, no finish (no affine / selects)
+                store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
+                store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
+            } else {
+                al.finish(ra);
+                bl.finish(rb);
+                store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
+                store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
+            }
+        }
+        if (VAR != 4) __syncthreads();
     }
 
     // epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -450,8 +526,40 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                       m_fast, ktiles, kps);
+    static const int variant = getenv("GOALNET_GEMM_VARIANT") ? atoi(getenv("GOALNET_GEMM_VARIANT")) : 0;
+    if (variant == 9)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 9>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 10)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 10>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 8)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 8>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 7)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 7>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 5)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 5>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 6)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 6>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 3)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 3>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 4)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 4>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 2)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 2>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else if (variant == 1)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 0>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
 }

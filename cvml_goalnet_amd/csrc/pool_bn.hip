@@ -9,6 +9,8 @@
 // Statistics are accumulated in fp64 and reduced through a fixed number (GOALNET_STAT_PARTS) of per-block
 // partial rows that a second kernel sums in a fixed order: deterministic, and accurate to the level of
 // ATen's CPU implementation (which accumulates float statistics in double).
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace goalnet;
@@ -212,6 +214,161 @@ __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict
     block_reduce_store<1>(accb, G, tid, smem, dbias_partials + (int64_t)blockIdx.x * C, C, C);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 kernels: one block = (frame slot, 32-channel slice). The three image rows a 3x3 / stride-1 window needs are
+// kept in a rolling LDS buffer, so every HBM byte is read exactly once (the v1 kernels above re-read each element
+// up to 9 times through L2 and lost it across XCDs: 2.2x the algorithmic traffic in rocprof). A 32-channel slice
+// of one pixel is one full 128-B line: 8 lanes x float4.
+// ------------------------------------------------------------------------------------------------
+constexpr int CS = 32;   // channels per block slice
+
+__device__ __forceinline__ void slice_reduce_store(double (&v)[2][4], int nv, int tid, double* red, double* out0, double* out1) {
+    // threads with the same (tid & 7) own the same 4 channels; 32 such threads per block
+    __syncthreads();
+    for (int a = 0; a < nv; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[(a * 256 + tid) * 4 + c] = v[a][c];
+    __syncthreads();
+    if (tid < 8) {
+        for (int a = 0; a < nv; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+                for (int t = tid; t < 256; t += 8) s += red[(a * 256 + t) * 4 + c];
+                (a == 0 ? out0 : out1)[tid * 4 + c] = s;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* __restrict__ y, float* __restrict__ p,
+                                                                 uint8_t* __restrict__ idx, double* __restrict__ partials,
+                                                                 int N, int Hc, int Wc, int C) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][Wc][CS] floats (>= 16 KB for the reduction)
+    const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
+    const int ccn = C / CS;
+    const int slot = blockIdx.x / ccn, c0 = (blockIdx.x % ccn) * CS + l8 * 4;
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int n = slot; n < N; n += PARTS) {
+        const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
+        float* pn = p + (int64_t)n * Hp * Wp * C + c0;
+        uint8_t* in = idx ? idx + (int64_t)n * Hp * Wp * C + c0 : nullptr;
+        __syncthreads();
+        for (int rr = 0; rr < 2; ++rr)
+            for (int x = px; x < Wc; x += 32)
+                *reinterpret_cast<float4*>(&smem[((rr * Wc) + x) * CS + l8 * 4]) =
+                    *reinterpret_cast<const float4*>(yn + ((int64_t)rr * Wc + x) * C);
+        for (int ph = 0; ph < Hp; ++ph) {
+            const int rnew = ph + 2;
+            for (int x = px; x < Wc; x += 32)
+                *reinterpret_cast<float4*>(&smem[(((rnew % 3) * Wc) + x) * CS + l8 * 4]) =
+                    *reinterpret_cast<const float4*>(yn + ((int64_t)rnew * Wc + x) * C);
+            __syncthreads();
+            for (int pw = px; pw < Wp; pw += 32) {
+                float4 best;
+                unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const float* row = &smem[((((ph + kh) % 3) * Wc) + pw) * CS + l8 * 4];
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float4 v = *reinterpret_cast<const float4*>(row + kw * CS);
+                        const unsigned k = kh * 3 + kw;
+                        if (k == 0) { best = v; continue; }
+                        if (v.x > best.x || v.x != v.x) { best.x = v.x; bi[0] = k; }
+                        if (v.y > best.y || v.y != v.y) { best.y = v.y; bi[1] = k; }
+                        if (v.z > best.z || v.z != v.z) { best.z = v.z; bi[2] = k; }
+                        if (v.w > best.w || v.w != v.w) { best.w = v.w; bi[3] = k; }
+                    }
+                }
+                const int64_t o = ((int64_t)ph * Wp + pw) * C;
+                *reinterpret_cast<float4*>(pn + o) = best;
+                if (in) *reinterpret_cast<uint32_t*>(in + o) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+                acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
+                acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
+                acc[0][2] += (double)best.z; acc[1][2] += (double)best.z * (double)best.z;
+                acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
+            }
+            __syncthreads();
+        }
+    }
+    double* row = partials + (int64_t)slot * 2 * C + (blockIdx.x % ccn) * CS;
+    slice_reduce_store(acc, 2, tid, reinterpret_cast<double*>(smem), row, row + C);
+}
+
+__global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                           const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                                           const float* __restrict__ coef3, float* __restrict__ dy,
+                                                           double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // dp [3][Wp][CS] floats, then idx [3][Wp][CS] bytes
+    const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
+    const int ccn = C / CS;
+    const int slot = blockIdx.x / ccn, cb = (blockIdx.x % ccn) * CS, c0 = cb + l8 * 4;
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(smem + 3 * Wp * CS);   // [3][Wp][8] words
+    const float4 ca = *reinterpret_cast<const float4*>(coef3 + c0);
+    const float4 cbv = *reinterpret_cast<const float4*>(coef3 + C + c0);
+    const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + c0);
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int n = slot; n < N; n += PARTS) {
+        const float* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
+        const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
+        const uint8_t* in = idx + (int64_t)n * Hp * Wp * C + c0;
+        const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
+        float* dyn = dy + (int64_t)n * Hc * Wc * C + c0;
+        __syncthreads();
+        for (int h = 0; h < Hc; ++h) {
+            if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
+                for (int x = px; x < Wp; x += 32) {
+                    const int64_t o = ((int64_t)h * Wp + x) * C;
+                    const float4 d = *reinterpret_cast<const float4*>(dzn + o);
+                    const float4 q = *reinterpret_cast<const float4*>(pn + o);
+                    float4 v;
+                    v.x = fmaf(ca.x, d.x, fmaf(cbv.x, q.x, cc.x));
+                    v.y = fmaf(ca.y, d.y, fmaf(cbv.y, q.y, cc.y));
+                    v.z = fmaf(ca.z, d.z, fmaf(cbv.z, q.z, cc.z));
+                    v.w = fmaf(ca.w, d.w, fmaf(cbv.w, q.w, cc.w));
+                    *reinterpret_cast<float4*>(&smem[(((h % 3) * Wp) + x) * CS + l8 * 4]) = v;
+                    sidx[(((h % 3) * Wp) + x) * 8 + l8] = *reinterpret_cast<const uint32_t*>(in + o);
+                }
+            }
+            __syncthreads();
+            for (int w = px; w < Wc; w += 32) {
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int ph = h - dh;
+                    if ((unsigned)ph >= (unsigned)Hp) continue;
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int pw = w - dw;
+                        if ((unsigned)pw >= (unsigned)Wp) continue;
+                        const int q = ((ph % 3) * Wp) + pw;
+                        const float4 v = *reinterpret_cast<const float4*>(&smem[q * CS + l8 * 4]);
+                        const uint32_t ii = sidx[q * 8 + l8];
+                        const unsigned k = dh * 3 + dw;
+                        a4.x += (ii & 0xffu) == k ? v.x : 0.f;
+                        a4.y += ((ii >> 8) & 0xffu) == k ? v.y : 0.f;
+                        a4.z += ((ii >> 16) & 0xffu) == k ? v.z : 0.f;
+                        a4.w += (ii >> 24) == k ? v.w : 0.f;
+                    }
+                }
+                const int64_t o = ((int64_t)h * Wc + w) * C;
+                const float4 yy = *reinterpret_cast<const float4*>(yn + o);
+                a4.x = yy.x > 0.f ? a4.x : 0.f;
+                a4.y = yy.y > 0.f ? a4.y : 0.f;
+                a4.z = yy.z > 0.f ? a4.z : 0.f;
+                a4.w = yy.w > 0.f ? a4.w : 0.f;
+                *reinterpret_cast<float4*>(dyn + o) = a4;
+                acc[0][0] += (double)a4.x; acc[0][1] += (double)a4.y; acc[0][2] += (double)a4.z; acc[0][3] += (double)a4.w;
+            }
+            __syncthreads();
+        }
+    }
+    double* row = dbias_partials + (int64_t)slot * C + cb;
+    slice_reduce_store(acc, 1, tid, reinterpret_cast<double*>(smem), row, row);
+}
+
 __global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restrict__ partials, int nparts, int64_t stride,
                                                           int C, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,7 +391,14 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bnstats_fwd: C=%d must be 4*2^k, <= 1024", C);
     GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
                "pool_bnstats_fwd: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
+    const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
+    if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
+        const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
+        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
+                           partials, N, Hc, Wc, C);
+    } else {
+        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
+    }
     GN_LAUNCH_CHECK("pool_bnstats_fwd");
     return 0;
 }
@@ -277,8 +441,15 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd: bad dims");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd: alignment");
-    hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
-                       dbias_partials, N, Hc, Wc, C);
+    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
+        const size_t need = lds < 8192 ? 8192 : lds;
+        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+                           dy, dbias_partials, N, Hc, Wc, C);
+    } else {
+        hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
+                           dbias_partials, N, Hc, Wc, C);
+    }
     GN_LAUNCH_CHECK("bnpool_bwd");
     return 0;
 }

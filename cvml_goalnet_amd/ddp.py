@@ -18,6 +18,7 @@ data/weight-gradient kernels that follow it; `finish()` makes the compute stream
 """
 from __future__ import annotations
 
+import os
 from typing import List, Tuple
 
 import torch
@@ -37,10 +38,12 @@ class GradSync:
     def __init__(self, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # GOALNET_DDP_FORCE=1: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.force = os.environ.get("GOALNET_DDP_FORCE") == "1" and dist.is_initialized()
         self._work = []
 
     def on_bucket(self, model, k: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         lo, hi = bucket_slices(model._specs, model._arena_numel)[k]
         self._work.append(dist.all_reduce(model._garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

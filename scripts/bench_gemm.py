@@ -1,0 +1,53 @@
+"""Micro-benchmark of the GEMM-engine entry points at the bench shapes (fewer frames). Prints TFLOP/s per op."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cvml_goalnet_amd import ops
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev = "cuda:0"
+torch.manual_seed(0)
+
+def timeit(fn, reps=4):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), sum(ts) / len(ts)
+
+def conv_case(name, h, w, cin, cout):
+    x = torch.randn(n, h, w, cin, device=dev); sc = torch.rand(cin, device=dev) + 0.5; sh = torch.randn(cin, device=dev) * 0.1
+    wt = torch.randn(cout, 3, 3, cin, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+    y = torch.empty(n, h, w, cout, device=dev)
+    fl = 2.0 * n * h * w * 9 * cin * cout
+    t, ta = timeit(lambda: ops.conv3x3_fwd(x, sc, sh, wt, b, True, y, n, h, w, cin, cout))
+    print(f"{name} fwd   : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    dy = torch.randn(n, h, w, cout, device=dev)
+    wtf = torch.empty(cout * 9 * cin, device=dev); ops.conv3x3_weight_flip(wt, wtf, cout, cin)
+    dx = torch.empty(n, h, w, cin, device=dev)
+    t, ta = timeit(lambda: ops.conv3x3_fwd(dy, None, None, wtf, None, False, dx, n, h, w, cout, cin))
+    print(f"{name} dgrad : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    dw = torch.empty(cout, 3, 3, cin, device=dev)
+    t, ta = timeit(lambda: ops.conv3x3_wgrad(x, sc, sh, dy, dw, n, h, w, cin, cout))
+    print(f"{name} wgrad : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+
+def lin5_case(hw3):
+    k = 512 * hw3
+    x = torch.randn(n, k, device=dev); w = torch.randn(512, k, device=dev) * 0.01; b = torch.randn(512, device=dev)
+    sc = torch.rand(512, device=dev) + 0.5; sh = torch.randn(512, device=dev) * 0.1
+    y = torch.empty(n, 512, device=dev); fl = 2.0 * n * k * 512
+    t, ta = timeit(lambda: ops.linear_fwd(x, w, b, y, relu=True, scale=sc, shift=sh, bnC=512))
+    print(f"linear5 fwd   : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s   ({w.numel() * 4 / t / 1e6:.0f} GB/s weight stream)")
+    dy = torch.randn(n, 512, device=dev); dx = torch.empty(n, k, device=dev)
+    t, ta = timeit(lambda: ops.linear_bwd_dx(dy, w, dx))
+    print(f"linear5 dX    : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
+    dw = torch.empty(512, k, device=dev)
+    t, ta = timeit(lambda: ops.linear_bwd_dw(dy, x, dw, scale=sc, shift=sh, bnC=512))
+    print(f"linear5 dW    : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
+
+print(f"N = {n} frames; variant = {os.environ.get('GOALNET_GEMM_VARIANT', '0')}")
+conv_case("conv3 72x72 256->512", 72, 72, 256, 512)
+conv_case("conv2 74x74  64->256", 74, 74, 64, 256)
+lin5_case(70 * 70)
