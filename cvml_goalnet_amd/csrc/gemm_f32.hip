@@ -41,14 +41,38 @@ __device__ __forceinline__ float4 f4fma(float4 v, float4 s, float4 t) {
 // ------------------------------------------------------------------------------------------------
 // operand loaders: global -> registers (4 x float4 per thread per K-tile)
 // ------------------------------------------------------------------------------------------------
+// The fp32 MFMA runs on the SIMD's fp32 lanes: every VALU instruction a wave issues between its MFMAs costs matrix
+// time one for one (measured, scripts/bench_gemm.py: conv3 forward 147 TFLOP/s with the staging instructions
+// removed, 126 with the first version's ~200 VALU per K-tile of 64-bit address arithmetic, masks and selects; moving
+// them to dedicated producer waves on the same SIMDs did not help). So the loaders are built to need (almost) no
+// VALU in the loop:
+//   * every load is a `buffer_load_dwordx4` through a per-block 128-bit buffer resource (SGPRs): the per-thread
+//     byte offset is a loop-invariant VGPR, the K-tile / tap / row-group advance is a scalar offset (SALU only);
+//   * rows past the end of a matrix and zero-padding taps rely on the buffer range check (out-of-range loads return
+//     0) instead of selects. Validity is always encoded in the loop-invariant voffset (an OOB marker) and
+//     num_records is the true extent, so the result does not depend on whether the scalar offset takes part in the
+//     range check (on gfx950 it does: measured); the resource is re-based per block / K-tile to span < 4 GB;
+//   * issue() only issues loads (they stay in flight under the current tile's MFMAs); finish() applies what is left
+//     (the BatchNorm affine, and a select only where a zero must survive the affine) right before the LDS write.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFF00u;   // a voffset beyond any resource's num_records
 
-// Every loader is split in two so that the global loads stay in flight under the MFMAs of the current
-// K-tile: issue() only issues unconditional loads (out-of-range rows / padding taps read a clamped, valid
-// address), finish() applies the zero fill and the affine right before the registers go to LDS. A branch
-// around a load would make hipcc wait for it at once (cdna_hip_programming.md §5, trap (c)).
 __device__ __forceinline__ float4 f4sel(bool v, float4 a) { return v ? a : f4zero(); }
 
-// K-contiguous matrix X[rows][K] (leading dim ld). Optional affine x*scale[k % C] + shift[k % C].
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ uint32_t clamp_u32(int64_t v) {
+    return v <= 0 ? 0u : (v > 0xFFFFFF00ll ? 0xFFFFFF00u : (uint32_t)v);
+}
+
+// K-contiguous matrix X[rows][K] (leading dim ld < 8M). Optional affine x*scale[k % C] + shift[k % C].
+// Rows past `rows` read 0 (before the affine: with AFFINE they hold `shift`, which only reaches output rows that
+// are never stored).
 template <bool AFFINE>
 struct KCLoader {
     struct P {
@@ -56,42 +80,46 @@ struct KCLoader {
         const float* scale; const float* shift; int bnC;
     };
     static constexpr bool KC = true;
-    const float* ptr[4];
-    unsigned okmask;
-    const float* scale; const float* shift;
-    int bnC, c4;
+    __amdgpu_buffer_rsrc_t rx, rsc, rsh;
+    unsigned voff[4], vaff;
+    int bnC;
     float4 sc, sh;
     __device__ KCLoader(const P& p, int row0, int tid) {
-        c4 = (tid & 7) * 4;
-        scale = p.scale; shift = p.shift; bnC = p.bnC;
-        const int rr = tid >> 3;
-        okmask = 0;
+        const int nrows = p.rows - row0 < BM ? p.rows - row0 : BM;
+        rx = make_rsrc(p.x + (int64_t)row0 * p.ld, clamp_u32((int64_t)nrows * p.ld * 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = row0 + rr + 32 * i;
-            const bool ok = row < p.rows;
-            okmask |= (ok ? 1u : 0u) << i;
-            ptr[i] = p.x + (int64_t)(ok ? row : 0) * p.ld + c4;
+            const int rl = (tid >> 3) + 32 * i;
+            voff[i] = rl < nrows ? (unsigned)(((int64_t)rl * p.ld + (tid & 7) * 4) * 4) : OOB;
+        }
+        bnC = p.bnC;
+        if (AFFINE) {
+            rsc = make_rsrc(p.scale, (uint32_t)p.bnC * 4);
+            rsh = make_rsrc(p.shift, (uint32_t)p.bnC * 4);
+            vaff = (unsigned)((tid & 7) * 16);
         }
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
-        const int k = kt * BK;
+        const unsigned k4 = (unsigned)kt * (BK * 4);
         if (AFFINE) {
-            const int ch = (k + c4) % bnC;
-            sc = *reinterpret_cast<const float4*>(scale + ch);
-            sh = *reinterpret_cast<const float4*>(shift + ch);
+            const unsigned ch4 = (unsigned)((kt * BK) % bnC) * 4;
+            sc = bload(rsc, vaff, ch4);
+            sh = bload(rsh, vaff, ch4);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(ptr[i] + k);
+        for (int i = 0; i < 4; ++i) r[i] = bload(rx, voff[i], k4);
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
+        if (AFFINE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = f4sel((okmask >> i) & 1u, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+            for (int i = 0; i < 4; ++i) r[i] = f4fma(r[i], sc, sh);
+        }
     }
 };
 
-// Row-contiguous matrix X[kred][cols] (leading dim ld): for a fixed reduction index the tile's columns
-// are contiguous. Optional affine per column (channel = col % C), fixed per thread.
+// Row-contiguous matrix X[kred][cols] (leading dim ld): for a fixed reduction index the tile's columns are
+// contiguous. Optional affine per column (channel = col % C), fixed per thread. The resource is re-based every K-tile
+// (32 reduction rows), so reduction rows past `kred` are out of range by construction.
 template <bool AFFINE>
 struct MCLoader {
     struct P {
@@ -99,42 +127,51 @@ struct MCLoader {
         const float* scale; const float* shift; int bnC;
     };
     static constexpr bool KC = false;
-    const float* base;
+    const float* x;
     int64_t ld;
     int kred, k0;
-    bool colok;
-    unsigned vmask;
+    unsigned voff[4];
+    bool partial;
     float4 sc, sh;
     __device__ MCLoader(const P& p, int col0, int tid) {
         const int col = col0 + (tid & 31) * 4;
-        colok = col < p.cols;
-        base = p.x + (colok ? col : 0);
-        ld = p.ld; kred = p.kred; k0 = tid >> 5;
+        const bool colok = col < p.cols;
+        x = p.x; ld = p.ld; kred = p.kred; k0 = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voff[i] = colok ? (unsigned)(((int64_t)(k0 + 8 * i) * p.ld + col) * 4) : OOB;
+        partial = false;
         if (AFFINE) {
             const int ch = (colok ? col : 0) % p.bnC;
             sc = *reinterpret_cast<const float4*>(p.scale + ch);
             sh = *reinterpret_cast<const float4*>(p.shift + ch);
+            if (!colok) sh = f4zero();          // columns past `cols` must stay 0 through the affine
         }
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
-        vmask = 0;
+        const int kbase = kt * BK;
+        const int nk = kred - kbase < BK ? kred - kbase : BK;
+        partial = nk < BK;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)kbase * ld, clamp_u32((int64_t)nk * ld * 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = kt * BK + k0 + 8 * i;
-            const bool v = colok && kk < kred;
-            vmask |= (v ? 1u : 0u) << i;
-            r[i] = *reinterpret_cast<const float4*>(base + (int64_t)(kk < kred ? kk : kred - 1) * ld);
-        }
+        for (int i = 0; i < 4; ++i) r[i] = bload(rx, voff[i], 0);
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
+        if (AFFINE) {
+            if (partial) {      // last K-tile only (wave-uniform): reduction rows past `kred` must be 0, not `shift`
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = f4sel((vmask >> i) & 1u, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+                for (int i = 0; i < 4; ++i) r[i] = f4sel(k0 + 8 * i < (kred & (BK - 1)), f4fma(r[i], sc, sh));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = f4fma(r[i], sc, sh);
+            }
+        }
     }
 };
 
 // im2col of an NHWC tensor for a 3x3 / stride 1 / pad 1 convolution: row m = (n,h,w), k = (kh,kw,ci).
-// The affine (BatchNorm of the producing block) is applied to in-bounds elements only: the reference pads
-// the BatchNorm OUTPUT with zeros (/root/reference/utils.py:154-156).
+// The affine (BatchNorm of the producing block) is applied to in-bounds elements only: the reference pads the
+// BatchNorm OUTPUT with zeros (/root/reference/utils.py:154-156). The resource starts W+1 pixels in front of the
+// tile's first pixel, so every tap shift is a non-negative scalar offset; padding taps get an out-of-range voffset.
 template <bool AFFINE>
 struct ConvALoader {
     struct P {
@@ -142,23 +179,26 @@ struct ConvALoader {
         const float* scale; const float* shift;
     };
     static constexpr bool KC = true;
-    const float* ptr[4];
+    __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned mask[4];
-    unsigned vmask;
-    const float* scale; const float* shift;
-    int W, C, c4;
+    unsigned voff, vaff, vmask;
+    int W, C;
     float4 sc, sh;
     __device__ ConvALoader(const P& p, int row0, int tid) {
-        c4 = (tid & 7) * 4;
-        W = p.W; C = p.C; scale = p.scale; shift = p.shift;
-        const int rr = tid >> 3;
+        W = p.W; C = p.C;
+        const int c4 = (tid & 7) * 4, rr = tid >> 3;
+        rx = make_rsrc(p.x + ((int64_t)row0 - (p.W + 1)) * p.C, (uint32_t)((BM + 2 * (p.W + 1)) * p.C * 4));
+        voff = (unsigned)((rr * p.C + c4) * 4);
+        if (AFFINE) {
+            rsc = make_rsrc(p.scale, (uint32_t)p.C * 4);
+            rsh = make_rsrc(p.shift, (uint32_t)p.C * 4);
+            vaff = (unsigned)(c4 * 4);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t m = (int64_t)row0 + rr + 32 * i;
             unsigned mk = 0;
-            int64_t mm = 0;
             if (m < p.M) {
-                mm = m;
                 const int w = (int)((unsigned)m % (unsigned)p.W);
                 const int h = (int)(((unsigned)m / (unsigned)p.W) % (unsigned)p.H);
 #pragma unroll
@@ -170,7 +210,6 @@ struct ConvALoader {
                     }
             }
             mask[i] = mk;
-            ptr[i] = p.x + mm * p.C + c4;
         }
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
@@ -178,37 +217,44 @@ struct ConvALoader {
         const int tap = k / C;
         const int ci = k - tap * C;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        const int64_t off = (int64_t)((kh - 1) * W + (kw - 1)) * C;
+        const unsigned s0 = (unsigned)(((kh * W + kw) * C + ci) * 4);     // shift by the resource's W+1 pixel lead
+        const unsigned rowstep = (unsigned)(32 * C * 4);
         if (AFFINE) {
-            sc = *reinterpret_cast<const float4*>(scale + ci + c4);
-            sh = *reinterpret_cast<const float4*>(shift + ci + c4);
+            sc = bload(rsc, vaff, (unsigned)ci * 4);
+            sh = bload(rsh, vaff, (unsigned)ci * 4);
         }
         vmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool v = (mask[i] >> tap) & 1u;
             vmask |= (v ? 1u : 0u) << i;
-            r[i] = *reinterpret_cast<const float4*>(ptr[i] + ci + (v ? off : 0));   // centre tap is always in bounds
+            r[i] = bload(rx, v ? voff : OOB, s0 + (unsigned)i * rowstep);
         }
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
+        if (AFFINE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = f4sel((vmask >> i) & 1u, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+            for (int i = 0; i < 4; ++i) r[i] = f4sel((vmask >> i) & 1u, f4fma(r[i], sc, sh));
+        }
     }
 };
 
 // B operand of the weight gradient: B(col = (tap, ci), red = m) = bnapply(x)[pixel m shifted by tap][ci].
+// Tap validity comes from a per-pixel border-code byte (bit0 h==0, bit1 h==H-1, bit2 w==0, bit3 w==W-1) prepared by
+// border_codes_kernel, so the loop needs no division; the resource is re-based per K-tile W+1 pixels in front of it.
 template <bool AFFINE>
 struct ConvWgradBLoader {
     struct P {
         const float* x; int H, W, C; int M;
         const float* scale; const float* shift;
+        const uint8_t* codes;
     };
     static constexpr bool KC = false;
-    const float* base;
-    int H, W, C, M, k0, dh, dw, tapoff;
+    const float* x;
+    __amdgpu_buffer_rsrc_t rcodes;
+    int W, C, M, k0, tapshift;
+    unsigned voff[4], badmask, code4;
     bool colok;
-    unsigned vmask;
     float4 sc, sh;
     __device__ ConvWgradBLoader(const P& p, int col0, int tid) {
         const int col = col0 + (tid & 31) * 4;
@@ -216,35 +262,51 @@ struct ConvWgradBLoader {
         const int cc = colok ? col : 0;
         const int tap = cc / p.C, ci = cc - tap * p.C;
         const int kh = tap / 3, kw = tap - 3 * kh;
-        dh = kh - 1; dw = kw - 1;
-        H = p.H; W = p.W; C = p.C; M = p.M; k0 = tid >> 5;
-        tapoff = (dh * p.W + dw) * p.C;
-        base = p.x + ci;
+        x = p.x; W = p.W; C = p.C; M = p.M; k0 = tid >> 5;
+        rcodes = make_rsrc(p.codes, (uint32_t)((p.M + 31) / 32 * 32));   // the range check covers voffset + soffset here
+        badmask = (kh == 0 ? 1u : 0u) | (kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : 0u) | (kw == 2 ? 8u : 0u);
+        tapshift = kh * p.W + kw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) voff[i] = colok ? (unsigned)(((k0 + 8 * i + tapshift) * p.C + ci) * 4) : OOB;
         if (AFFINE) {
             sc = *reinterpret_cast<const float4*>(p.scale + ci);
             sh = *reinterpret_cast<const float4*>(p.shift + ci);
         }
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
-        vmask = 0;
+        const int mbase = kt * BK;
+        // pixels [mbase - (W+1), mbase + 32 + (W+1)) clipped to the tensor: taps past the end are out of range (0);
+        // in-tensor padding taps are zeroed in finish() by the border code
+        const int64_t lead = (int64_t)mbase - (W + 1);
+        const int64_t last = (int64_t)mbase + BK + (W + 1) < M ? (int64_t)mbase + BK + (W + 1) : M;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + lead * C, clamp_u32((last - lead) * C * 4));
+        if (lead < 0) {      // first K-tiles only (wave-uniform): never touch memory in front of the tensor
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = kt * BK + k0 + 8 * i;
-            bool v = colok && m < M;
-            m = m < M ? m : M - 1;
-            const unsigned t = (unsigned)m / (unsigned)W;
-            const int w = m - (int)t * W;
-            const int h = (int)(t % (unsigned)H);
-            v = v && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W;
-            vmask |= (v ? 1u : 0u) << i;
-            r[i] = *reinterpret_cast<const float4*>(base + (int64_t)m * C + (v ? tapoff : 0));
+            for (int i = 0; i < 4; ++i) r[i] = bload(rx, mbase + k0 + 8 * i + tapshift < W + 1 ? OOB : voff[i], 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = bload(rx, voff[i], 0);
         }
+        code4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)      // codes[] is padded to a multiple of 32 entries, pixels >= M carry 0xF
+            code4 |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rcodes, (int)(k0 + 8 * i), mbase, 0) << (8 * i);
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = f4sel((vmask >> i) & 1u, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+        for (int i = 0; i < 4; ++i) {
+            const bool v = colok && (((code4 >> (8 * i)) & badmask) == 0);
+            r[i] = f4sel(v, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+        }
     }
 };
+
+__global__ __launch_bounds__(256) void border_codes_kernel(uint8_t* __restrict__ codes, int M, int Mpad, int H, int W) {
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < Mpad; m += gridDim.x * blockDim.x) {
+        const int w = m % W, h = (m / W) % H;
+        codes[m] = m < M ? (uint8_t)((h == 0 ? 1 : 0) | (h == H - 1 ? 2 : 0) | (w == 0 ? 4 : 0) | (w == W - 1 ? 8 : 0)) : (uint8_t)0xF;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // epilogue
@@ -285,85 +347,121 @@ __device__ __forceinline__ void store_tile(float* l, const float4 (&r)[4], int t
     }
 }
 
+// Fragment reads of one group (8 k) for the wave's two 32-row fragments of one operand.
+//   K-contiguous image [row][36]: one ds_read_b128 per fragment = 4 MFMA steps of that fragment.
+//   row-contiguous image [k][128]: one ds_read_b64 per MFMA step serves BOTH fragments: lane r takes rows 2r, 2r+1 of
+//     the wave's 64-row strip, i.e. fragment f holds the rows 2i + f (i = MFMA row index) — store_acc() undoes it.
 template <bool KC>
-__device__ __forceinline__ void read_frag(const float* l, int rowbase, int s, int r, int h, float (&f)[4]) {
+__device__ __forceinline__ void read_group(const float* l, int strip, int s, int r, int h, float (&f)[2][4]) {
     if (KC) {
-        const float4 t = *reinterpret_cast<const float4*>(&l[(rowbase + r) * LDK + 8 * s + 4 * h]);
-        f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
-    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = l[(8 * s + 4 * h + j) * LDR + rowbase + r];
-    }
-}
-
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void read_group(const float* la, const float* lb, int wm, int wn, int s, int r, int h,
-                                           float (&a)[2][4], float (&b)[2][4]) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        read_frag<AKC>(la, wm * 64 + f * 32, s, r, h, a[f]);
-        read_frag<BKC>(lb, wn * 64 + f * 32, s, r, h, b[f]);
-    }
-}
-
-__device__ __forceinline__ void mfma_group(const float (&a)[2][4], const float (&b)[2][4], f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < 2; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm][j], b[fn][j], acc[fm][fn], 0, 0, 0);
-    }
-}
-
-// One K-tile = 4 groups of 16 MFMAs. VAR 0: fragments are read right before their group (hipcc sinks the reads to
-// the end of the previous group, exposing ~100 cycles of LDS latency per group). VAR 1: software-pipelined — the
-// fragments of group s+1 are in flight while group s runs on the matrix pipe (two fragment register sets).
-template <bool AKC, bool BKC, int VAR>
-__device__ __forceinline__ void compute_tile(const float* la, const float* lb, f32x16 (&acc)[2][2],
-                                             int wm, int wn, int r, int h) {
-    if (VAR == 0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float a[2][4], b[2][4];
-            read_group<AKC, BKC>(la, lb, wm, wn, s, r, h, a, b);
-            mfma_group(a, b, acc);
+        for (int q = 0; q < 2; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&l[(strip + q * 32 + r) * LDK + 8 * s + 4 * h]);
+            f[q][0] = t.x; f[q][1] = t.y; f[q][2] = t.z; f[q][3] = t.w;
         }
     } else {
-        float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
-        read_group<AKC, BKC>(la, lb, wm, wn, 0, r, h, a0, b0);
-        read_group<AKC, BKC>(la, lb, wm, wn, 1, r, h, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(a0, b0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        read_group<AKC, BKC>(la, lb, wm, wn, 2, r, h, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(a1, b1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        read_group<AKC, BKC>(la, lb, wm, wn, 3, r, h, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(a0, b0, acc);
-        mfma_group(a1, b1, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 t = *reinterpret_cast<const float2*>(&l[(8 * s + 4 * h + j) * LDR + strip + 2 * r]);
+            f[0][j] = t.x; f[1][j] = t.y;
+        }
     }
 }
 
-template <class AL, class BL, int VAR>
+// One K-tile = 4 groups (8 k each) of 16 MFMAs on the wave's 2 x 2 accumulator tiles.
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void compute_tile(const float* la, const float* lb, f32x16 (&acc)[2][2],
+                                             int wm, int wn, int r, int h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float a[2][4], b[2][4];
+        read_group<AKC>(la, wm * 64, s, r, h, a);
+        read_group<BKC>(lb, wn * 64, s, r, h, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < 2; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fm][j], b[fn][j], acc[fm][fn], 0, 0, 0);
+        }
+    }
+}
+
+// epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Each mode is a branch-free body under a wave-uniform switch: a branch around a load inside the
+// unrolled store loop would serialise 64 dependent memory round trips.
+// AIL / BIL: the A / B operand was read row-contiguous, so fragment f holds the strip's rows (cols) 2i + f.
+template <bool AIL, bool BIL>
+__device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2][2], int tm, int tn, int split,
+                                          int wm, int wn, int r, int h) {
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) {
+            const int col = tn * BN + wn * 64 + (BIL ? 2 * r + fn : fn * 32 + r);
+            const bool colok = col < ep.cols;
+            const int colc = colok ? col : 0;
+            constexpr int RS = AIL ? 2 : 1;                                   // row step per MFMA row index
+            const int64_t row0 = (int64_t)tm * BM + wm * 64 + (AIL ? fm : fm * 32) + RS * 4 * h;
+            if (mode == EPI_RAW) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e];
+                }
+            } else if (mode == EPI_BIAS_RELU) {
+                const float bv = ep.bias ? ep.bias[colc] : 0.f;
+                const float lo = ep.relu ? 0.f : -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[fm][fn][e] + bv, lo);
+                }
+            } else if (mode == EPI_MUL) {
+                float mv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    mv[e] = ep.mul[(row < ep.rows ? row : ep.rows - 1) * ep.ldmul + colc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e] * mv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = epi_apply(ep, acc[fm][fn][e], row, col);
+                }
+            }
+        }
+}
+
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int m_fast, int& tm, int& tn) {
+    const unsigned v = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    if (m_fast) { tm = (int)(v % (unsigned)tiles_m); tn = (int)(v / (unsigned)tiles_m); }
+    else        { tn = (int)(v % (unsigned)tiles_n); tm = (int)(v / (unsigned)tiles_n); }
+}
+
+// ---- uniform kernel: every wave stages and computes (256 threads, 2 blocks per CU) ------------------------------
+template <class AL, class BL, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split) {
-    __shared__ __attribute__((aligned(16))) float lds[VAR == 8 ? 4 : 2][2][OP_FLOATS];   // VAR 8: 1 block/CU experiment
+    __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
     const int tid = threadIdx.x;
-    if (VAR == 8 && ktiles < 0) lds[3][1][tid] = 0.f;
-    const unsigned v = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
     int tm, tn;
-    if (m_fast) { tm = (int)(v % (unsigned)tiles_m); tn = (int)(v / (unsigned)tiles_m); }
-    else        { tn = (int)(v % (unsigned)tiles_n); tm = (int)(v / (unsigned)tiles_n); }
+    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
     const int split = blockIdx.y;
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles, kt0 + ktiles_per_split);
 
-    AL al(ap, VAR == 2 ? 0 : tm * BM, tid);      // VAR 2: timing experiment, every block reads M-tile 0 (L2-resident)
+    AL al(ap, tm * BM, tid);
     BL bl(bp, tn * BN, tid);
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -388,113 +486,98 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
         store_tile<BL::KC>(lds[0][1], rb, tid);
     }
     __syncthreads();
-    if (VAR == 7) {
-        // One basic block per K-tile (staging is unconditional: the last iteration re-stages the final tile into the
-        // spare buffer), so that the scheduler can follow the interleave below: every fp32 MFMA occupies the matrix
-        // pipe for 64 cycles, during which the SAME wave can issue the address arithmetic, global loads, LDS reads,
-        // affine and LDS writes of the staging — instead of running them as a separate phase in front of the MFMAs.
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            const int nxt = kt + 1 < kt1 ? kt + 1 : kt;
-            al.issue(nxt, ra);
-            bl.issue(nxt, rb);
-            compute_tile<AL::KC, BL::KC, 0>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
-            al.finish(ra);
-            bl.finish(rb);
-            store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
-            store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
-            // ---- interleave: masks 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
-            __builtin_amdgcn_sched_group_barrier(0x100, AL::KC && BL::KC ? 4 : 8, 0);
-#pragma unroll
-            for (int i = 0; i < 64; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 40) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    if (i % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                }
-                if (i % 16 == 8 && i < 48) __builtin_amdgcn_sched_group_barrier(0x100, AL::KC && BL::KC ? 4 : 8, 0);
-            }
-            __syncthreads();
-        }
-    } else
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
-        const bool more = (VAR == 3 || VAR == 4) ? false : kt + 1 < kt1;   // VAR 3/4: timing experiments (no staging)
-        if (more) {
-            if (VAR != 9) al.issue(kt + 1, ra);       // VAR 9: B loads only; VAR 10: A loads only (timing experiments)
-            if (VAR != 10) bl.issue(kt + 1, rb);
+        const bool more = kt + 1 < kt1;
+        if (more && EXP != 2) {          // EXP: timing experiments only (results are wrong)
+            al.issue(kt + 1, ra);
+            bl.issue(kt + 1, rb);
         }
-        compute_tile<AL::KC, BL::KC, (VAR == 1 ? 1 : 0)>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
         if (more) {
-            if (VAR == 5 || VAR == 9 || VAR == 10) {          // timing experiment: loads only, no finish / LDS write
+            if (EXP == 1) {              // loads only
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
                     asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
                 }
-            } else if (VAR == 6) {   // timing experiment: loads + LDS write, no finish (no affine / selects)
+            } else {                     // EXP 2: LDS writes only (stale registers)
+                if (EXP == 0) { al.finish(ra); bl.finish(rb); }
                 store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
                 store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
-            } else {
+            }
+        }
+        __syncthreads();
+    }
+    store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
+}
+
+// ---- wave-specialised kernel: 512 threads = 4 consumer waves (MFMA only) + 4 producer waves (staging only) ----------
+// Measured on the uniform kernel (scripts/bench_gemm.py, conv3 forward): 126 TFLOP/s; with the staging instructions
+// removed from the loop 147; with only the global loads + their address arithmetic kept 131. An fp32 MFMA owns the
+// matrix pipe for 64 cycles, but a wave issues in order, so its own ~60 VALU + 10 VMEM + 8 LDS-write staging
+// instructions per K-tile sit between its MFMAs and the co-resident wave only partly fills the hole. Here the
+// consumer waves' instruction stream is {16 ds_read_b128, 64 MFMA, s_barrier} per K-tile; the producers run the
+// loaders (same code as above) on the same SIMDs' VALU/VMEM/LDS ports. Waves w and w+4 of a workgroup share a SIMD.
+template <class AL, class BL>
+__global__ __launch_bounds__(512, 4) void gemm_f32_ws_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
+                                                             int tiles_m, int tiles_n, int m_fast,
+                                                             int ktiles, int ktiles_per_split) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
+    const int tid = threadIdx.x;
+    int tm, tn;
+    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
+    const int split = blockIdx.y;
+    const int kt0 = split * ktiles_per_split;
+    const int kt1 = min(ktiles, kt0 + ktiles_per_split);
+
+    if (tid >= 256) {
+        // ---------------- producers ----------------
+        const int pt = tid - 256;
+        AL al(ap, tm * BM, pt);
+        BL bl(bp, tn * BN, pt);
+        float4 ra[4], rb[4];
+        if (kt0 < kt1) {
+            al.issue(kt0, ra);
+            bl.issue(kt0, rb);
+            al.finish(ra);
+            bl.finish(rb);
+            store_tile<AL::KC>(lds[0][0], ra, pt);
+            store_tile<BL::KC>(lds[0][1], rb, pt);
+        }
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) {
+                al.issue(kt + 1, ra);
+                bl.issue(kt + 1, rb);
                 al.finish(ra);
                 bl.finish(rb);
-                store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
-                store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
+                store_tile<AL::KC>(lds[cur ^ 1][0], ra, pt);
+                store_tile<BL::KC>(lds[cur ^ 1][1], rb, pt);
             }
+            __syncthreads();
         }
-        if (VAR != 4) __syncthreads();
+        return;
     }
-
-    // epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // Each mode is a branch-free body under a wave-uniform switch: a branch around a load inside the
-    // unrolled store loop would serialise 64 dependent memory round trips.
-    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
-    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+    // ---------------- consumers ----------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-            const int col = tn * BN + wn * 64 + fn * 32 + r;
-            const bool colok = col < ep.cols;
-            const int colc = colok ? col : 0;
-            const int64_t row0 = (int64_t)tm * BM + wm * 64 + fm * 32 + 4 * h;
-            if (mode == EPI_RAW) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e];
-                }
-            } else if (mode == EPI_BIAS_RELU) {
-                const float bv = ep.bias ? ep.bias[colc] : 0.f;
-                const float lo = ep.relu ? 0.f : -INFINITY;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[fm][fn][e] + bv, lo);
-                }
-            } else if (mode == EPI_MUL) {
-                float mv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    mv[e] = ep.mul[(row < ep.rows ? row : ep.rows - 1) * ep.ldmul + colc];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e] * mv[e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = epi_apply(ep, acc[fm][fn][e], row, col);
-                }
-            }
-        }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        __syncthreads();
+    }
+    store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
 }
 
 // sums `nsplit` raw slabs (deterministic order) and applies the epilogue. cols % 4 == 0.
@@ -526,39 +609,17 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
-    static const int variant = getenv("GOALNET_GEMM_VARIANT") ? atoi(getenv("GOALNET_GEMM_VARIANT")) : 0;
-    if (variant == 9)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 9>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 10)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 10>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 8)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 8>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 7)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 7>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 5)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 5>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 6)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 6>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 3)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 3>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 4)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 4>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 2)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 2>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else if (variant == 1)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+    static const int ws = getenv("GOALNET_GEMM_WS") ? atoi(getenv("GOALNET_GEMM_WS")) : 0;
+    static const int ex = getenv("GOALNET_GEMM_EXP") ? atoi(getenv("GOALNET_GEMM_EXP")) : 0;
+    if (ex == 1)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
+    else if (ex == 2)
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 2>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
+    else if (ws)
+        hipLaunchKernelGGL((gemm_f32_ws_kernel<AL, BL>), grid, dim3(512), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
                            m_fast, ktiles, kps);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 0>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
                            m_fast, ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
@@ -626,9 +687,11 @@ static int wgrad_splits(int64_t M, int Cin, int Cout) {
     return (ktiles + kps - 1) / kps;
 }
 
+static size_t wgrad_codes_bytes(int64_t M) { return (size_t)((M + 31) / 32 * 32 + 255) / 256 * 256; }
+
 size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     const int64_t M = (int64_t)N * H * W;
-    return (size_t)wgrad_splits(M, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
+    return wgrad_codes_bytes(M) + (size_t)wgrad_splits(M, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
 }
 
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
@@ -646,19 +709,28 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     const int nsplit = wgrad_splits(M, Cin, Cout);
     const int ktiles = (int)((M + BK - 1) / BK);
     const int64_t slab = (int64_t)Cout * 9 * Cin;
+    uint8_t* codes = (uint8_t*)ws;
+    float* slabs = (float*)((char*)ws + wgrad_codes_bytes(M));
+    {
+        const int Mpad = (int)((M + 31) / 32 * 32);
+        int blocks = (Mpad + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(border_codes_kernel, dim3(blocks), dim3(256), 0, st, codes, (int)M, Mpad, H, W);
+        GN_LAUNCH_CHECK("conv3x3_wgrad.codes");
+    }
     MCLoader<false>::P ap{dy, Cout, Cout, (int)M, nullptr, nullptr, 1};
-    EpiP ep{EPI_RAW, (float*)ws, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
+    EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
     int rc;
     if (scale) {
-        ConvWgradBLoader<true>::P bp{x, H, W, Cin, (int)M, scale, shift};
+        ConvWgradBLoader<true>::P bp{x, H, W, Cin, (int)M, scale, shift, codes};
         rc = launch_gemm<MCLoader<false>, ConvWgradBLoader<true>>("conv3x3_wgrad", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
     } else {
-        ConvWgradBLoader<false>::P bp{x, H, W, Cin, (int)M, nullptr, nullptr};
+        ConvWgradBLoader<false>::P bp{x, H, W, Cin, (int)M, nullptr, nullptr, codes};
         rc = launch_gemm<MCLoader<false>, ConvWgradBLoader<false>>("conv3x3_wgrad", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
     }
     if (rc) return rc;
     EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
-    return launch_reduce("conv3x3_wgrad.reduce", (const float*)ws, nsplit, slab, er, st);
+    return launch_reduce("conv3x3_wgrad.reduce", slabs, nsplit, slab, er, st);
 }
 
 static int linear_splits(int M, int64_t K, int J) {
