@@ -29,9 +29,13 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDK = BK + 4;           // K-contiguous operand: LDS row stride in floats (pad = one b128)
 constexpr int LDR = 128;              // row-contiguous operand: LDS stride between k rows
-constexpr int OP_FLOATS = BM * LDK;   // 4608 floats (>= BK * LDR = 4096)
+constexpr int OP_FLOATS = BM * BK;    // 4096 floats = 16 KB per operand per stage (both images)
+
+// K-contiguous LDS image: [128 rows][32 floats], unpadded (an LDS-DMA wave-instruction writes 1 KB contiguously, so
+// rows cannot be padded) with the eight 16-B chunks of a row XOR-swizzled by (row >> 1) & 7: the 16 lanes of a
+// ds_read_b128 group (rows {0-3,12-15,20-27} + ...) then land on 16 distinct 4-bank slots -> conflict-free.
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4fma(float4 v, float4 s, float4 t) {
@@ -339,7 +343,7 @@ __device__ __forceinline__ void store_tile(float* l, const float4 (&r)[4], int t
     if (KC) {
         const int c4 = (tid & 7) * 4, row = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&l[(row + 32 * i) * LDK + c4]) = r[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&l[kc_off(row + 32 * i, c4 >> 2)]) = r[i];
     } else {
         const int r4 = (tid & 31) * 4, k = tid >> 5;
 #pragma unroll
@@ -348,7 +352,7 @@ __device__ __forceinline__ void store_tile(float* l, const float4 (&r)[4], int t
 }
 
 // Fragment reads of one group (8 k) for the wave's two 32-row fragments of one operand.
-//   K-contiguous image [row][36]: one ds_read_b128 per fragment = 4 MFMA steps of that fragment.
+//   K-contiguous image (kc_off): one ds_read_b128 per fragment = 4 MFMA steps of that fragment.
 //   row-contiguous image [k][128]: one ds_read_b64 per MFMA step serves BOTH fragments: lane r takes rows 2r, 2r+1 of
 //     the wave's 64-row strip, i.e. fragment f holds the rows 2i + f (i = MFMA row index) — store_acc() undoes it.
 template <bool KC>
@@ -356,7 +360,7 @@ __device__ __forceinline__ void read_group(const float* l, int strip, int s, int
     if (KC) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(&l[(strip + q * 32 + r) * LDK + 8 * s + 4 * h]);
+            const float4 t = *reinterpret_cast<const float4*>(&l[kc_off(strip + q * 32 + r, 2 * s + h)]);
             f[q][0] = t.x; f[q][1] = t.y; f[q][2] = t.z; f[q][3] = t.w;
         }
     } else {
@@ -448,8 +452,13 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int m_fa
     else        { tn = (int)(v % (unsigned)tiles_n); tm = (int)(v / (unsigned)tiles_n); }
 }
 
-// ---- uniform kernel: every wave stages and computes (256 threads, 2 blocks per CU) ------------------------------
-template <class AL, class BL, int EXP = 0>
+// ---- the kernel: 256 threads, every wave stages and computes, 2 blocks per CU ---------------------------------------
+// Measured ceilings on conv3 forward (scripts/bench_gemm.py, N = 128, 2.37 GHz): 147 TFLOP/s with no staging in the
+// loop, 135 with only the global loads or only the LDS writes, 127 with both. Two restructurings were built, found
+// correct and measured without gain, and removed again (git history): 4 MFMA-only consumer waves + 4 staging-only
+// producer waves per block (122), and LDS-DMA (`buffer_load ... lds`) staging of the operands that need no
+// transform (123-127): the cost follows the bytes moved into LDS, not the instruction mix of the MFMA waves.
+template <class AL, class BL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split) {
@@ -489,92 +498,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
-        if (more && EXP != 2) {          // EXP: timing experiments only (results are wrong)
+        if (more) {
+            // the buffer being filled was last read in iteration kt-1, which every wave left through the barrier
             al.issue(kt + 1, ra);
             bl.issue(kt + 1, rb);
         }
         compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
         if (more) {
-            if (EXP == 1) {              // loads only
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
-                    asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
-                }
-            } else {                     // EXP 2: LDS writes only (stale registers)
-                if (EXP == 0) { al.finish(ra); bl.finish(rb); }
-                store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
-                store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
-            }
-        }
-        __syncthreads();
-    }
-    store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
-}
-
-// ---- wave-specialised kernel: 512 threads = 4 consumer waves (MFMA only) + 4 producer waves (staging only) ----------
-// Measured on the uniform kernel (scripts/bench_gemm.py, conv3 forward): 126 TFLOP/s; with the staging instructions
-// removed from the loop 147; with only the global loads + their address arithmetic kept 131. An fp32 MFMA owns the
-// matrix pipe for 64 cycles, but a wave issues in order, so its own ~60 VALU + 10 VMEM + 8 LDS-write staging
-// instructions per K-tile sit between its MFMAs and the co-resident wave only partly fills the hole. Here the
-// consumer waves' instruction stream is {16 ds_read_b128, 64 MFMA, s_barrier} per K-tile; the producers run the
-// loaders (same code as above) on the same SIMDs' VALU/VMEM/LDS ports. Waves w and w+4 of a workgroup share a SIMD.
-template <class AL, class BL>
-__global__ __launch_bounds__(512, 4) void gemm_f32_ws_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
-                                                             int tiles_m, int tiles_n, int m_fast,
-                                                             int ktiles, int ktiles_per_split) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
-    const int tid = threadIdx.x;
-    int tm, tn;
-    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
-    const int split = blockIdx.y;
-    const int kt0 = split * ktiles_per_split;
-    const int kt1 = min(ktiles, kt0 + ktiles_per_split);
-
-    if (tid >= 256) {
-        // ---------------- producers ----------------
-        const int pt = tid - 256;
-        AL al(ap, tm * BM, pt);
-        BL bl(bp, tn * BN, pt);
-        float4 ra[4], rb[4];
-        if (kt0 < kt1) {
-            al.issue(kt0, ra);
-            bl.issue(kt0, rb);
             al.finish(ra);
             bl.finish(rb);
-            store_tile<AL::KC>(lds[0][0], ra, pt);
-            store_tile<BL::KC>(lds[0][1], rb, pt);
+            store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
+            store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
         }
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            if (kt + 1 < kt1) {
-                al.issue(kt + 1, ra);
-                bl.issue(kt + 1, rb);
-                al.finish(ra);
-                bl.finish(rb);
-                store_tile<AL::KC>(lds[cur ^ 1][0], ra, pt);
-                store_tile<BL::KC>(lds[cur ^ 1][1], rb, pt);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // ---------------- consumers ----------------
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
         __syncthreads();
     }
     store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
@@ -609,18 +544,8 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
-    static const int ws = getenv("GOALNET_GEMM_WS") ? atoi(getenv("GOALNET_GEMM_WS")) : 0;
-    static const int ex = getenv("GOALNET_GEMM_EXP") ? atoi(getenv("GOALNET_GEMM_EXP")) : 0;
-    if (ex == 1)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
-    else if (ex == 2)
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, 2>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
-    else if (ws)
-        hipLaunchKernelGGL((gemm_f32_ws_kernel<AL, BL>), grid, dim3(512), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                           m_fast, ktiles, kps);
+    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                       m_fast, ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
