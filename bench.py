@@ -36,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (not the 2:1-sparsity marketing figure)
 FRAMES_PER_CLIP = 16
 
 
@@ -109,6 +110,8 @@ def main():
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "f32"),
+                    help="f32 = the reference's arithmetic on fp32 MFMA; bf16 = bf16-MFMA contractions, fp32 accumulate")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,7 +138,7 @@ def main():
     h = w = args.hw
     seed = synth.BASE_SEED + rank
     torch.manual_seed(1234)                                   # same initial weights on every rank
-    model = AVM(audio_included=not args.no_audio, device=dev, seed=seed)
+    model = AVM(audio_included=not args.no_audio, device=dev, seed=seed, precision="bf16" if args.dtype == "bf16" else "fp32")
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if args.no_audio:
         aud = None
@@ -169,7 +172,7 @@ def main():
             "metric": "training clips/sec at batch 64, 16-frame 224² clips; logit MAE vs CPU ref",
             "value": clips / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"AVM train step (forward + broadcast-MSE + backward + fused Adam), {args.clips} clips x 16 frames = "
                                    f"{n} frames of 3x{h}x{w} + 30x30 MFCC per GPU; dropout live (device masks), BatchNorm train mode",
                        "frames_per_gpu": n, "h": h, "w": w, "global_clips_per_step": args.clips * world,
@@ -188,9 +191,14 @@ def main():
                     traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "kernel": "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)",
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+            kname = ("gemm_bf16_kernel<ConvALoaderH, KCLoaderH> (conv2 + conv3 forward, bf16 MFMA implicit GEMM)" if args.dtype == "bf16"
+                     else "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)")
+            if args.dtype == "bf16":
+                traffic = None
+            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                               "frac": achieved / peak, "traffic": traffic,
+                               "kernel": kname,
                                "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms),
                                "algorithmic_flops_per_launch": sum(fl) / len(fl)}
             others = {}

@@ -70,9 +70,14 @@ class _Spec:
 
 
 class AVM(nn.Module):
-    def __init__(self, audio_included, device=None, seed: int = BASE_SEED):
+    def __init__(self, audio_included, device=None, seed: int = BASE_SEED, precision: str = "fp32"):
         super().__init__()
         self.audio_included = audio_included                      # utils.py:235
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 MFMA contractions)")
+        # "bf16": the dense contractions (conv2/conv3 forward + data gradient, linear5 forward) run on the bf16 matrix
+        # cores with fp32 accumulation; statistics, master weights, gradients and Adam stay fp32
+        self.precision = precision
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         self._device = torch.device(device) if device is not None else None
@@ -375,12 +380,28 @@ class AVM(nn.Module):
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
         y2 = torch.empty(n, hp1, wp1, 256, dtype=F32, device=dev)
-        self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
-                    p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+        bf = self.precision == "bf16"
+        BF16 = torch.bfloat16
+        if bf:
+            xh1 = ops.bn_apply_bf16(p1, st1[2], st1[3], torch.empty(p1.shape, dtype=BF16, device=dev), 64)
+            w2b = ops.cast_bf16(P("visbl.conv2.weight"), torch.empty(256 * 9 * 64, dtype=BF16, device=dev))
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16,
+                        xh1, w2b, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+            del xh1
+        else:
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
+                        p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
         y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
-        self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
-                    p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+        if bf:
+            xh2 = ops.bn_apply_bf16(p2, st2[2], st2[3], torch.empty(p2.shape, dtype=BF16, device=dev), 256)
+            w3b = ops.cast_bf16(P("visbl.conv3.weight"), torch.empty(512 * 9 * 256, dtype=BF16, device=dev))
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16,
+                        xh2, w3b, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+            del xh2
+        else:
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
+                        p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
         p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save)
 
         fw = 640 if self.audio_included else 512
@@ -388,8 +409,15 @@ class AVM(nn.Module):
         cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
         mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         k5 = 512 * hp3 * wp3
-        ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
-                       scale=st3[2], shift=st3[3], bnC=512, dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+        if bf:
+            xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
+            w5b = ops.cast_bf16(P("visbl.linear5.weight"), torch.empty(512 * k5, dtype=BF16, device=dev))
+            ops.linear_fwd_bf16(xh3.view(n, k5), w5b, P("visbl.linear5.bias"), cat[:, voff:], relu=True,
+                                dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+            del xh3, w5b
+        else:
+            ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
+                           scale=st3[2], shift=st3[3], bnC=512, dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
 
         a1 = a2 = None
         if self.audio_included:
@@ -496,8 +524,15 @@ class AVM(nn.Module):
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         dbn2 = torch.empty(n, hp2, wp2, 256, dtype=F32, device=dev)
-        self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
-                    dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
+        if self.precision == "bf16":
+            dyb = ops.cast_bf16(dy3, torch.empty(dy3.shape, dtype=torch.bfloat16, device=dev))
+            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
+            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16,
+                        dyb, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
+            del dyb
+        else:
+            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
+                        dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
         del dy3
 
         # block 2 (utils.py:179-182)
@@ -509,8 +544,15 @@ class AVM(nn.Module):
         wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
-        self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
-                    dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
+        if self.precision == "bf16":
+            dyb = ops.cast_bf16(dy2, torch.empty(dy2.shape, dtype=torch.bfloat16, device=dev))
+            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
+            self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_bf16,
+                        dyb, wtb, None, False, dbn1, n, hp1, wp1, 256, 64)
+            del dyb
+        else:
+            self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
+                        dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
         del dy2
 
         # block 1 (utils.py:174-177); conv1's input needs no gradient

@@ -1,0 +1,100 @@
+// Shared pieces of the GEMM engines (gemm_f32.hip: fp32 MFMA, gemm_bf16.hip: bf16 MFMA): epilogue parameters,
+// the accumulator -> memory epilogue for the 32x32 MFMA C/D layout (identical for every dtype on gfx950), the
+// XCD-aware tile order and the split-K slab reduction.
+#pragma once
+#include "common.h"
+
+namespace goalnet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GEMM_BM = 128, GEMM_BN = 128;
+
+// ------------------------------------------------------------------------------------------------
+// epilogue
+// ------------------------------------------------------------------------------------------------
+enum { EPI_RAW = 0, EPI_BIAS_RELU = 1, EPI_MUL = 2, EPI_FULL = 3 };
+
+struct EpiP {
+    int mode;
+    float* out; int64_t ld; int rows; int cols;
+    const float* bias; int relu;
+    const float* mul; int64_t ldmul;      // elementwise multiplier (dropout mask forward, saved mult backward)
+    float* mult_out; int64_t ldmo;        // (pre-activation > 0) * mul, saved for backward
+    int64_t slab_stride;                  // > 0: raw partial sums to out + split * slab_stride (ld = cols)
+};
+
+__device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {
+    if (e.bias) v += e.bias[col];
+    float g = 1.f;
+    if (e.relu) { g = v > 0.f ? 1.f : 0.f; v = v > 0.f ? v : 0.f; }
+    if (e.mul) { const float m = e.mul[row * e.ldmul + col]; v *= m; g *= m; }
+    if (e.mult_out) e.mult_out[row * e.ldmo + col] = g;
+    return v;
+}
+
+
+// epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// Each mode is a branch-free body under a wave-uniform switch: a branch around a load inside the
+// unrolled store loop would serialise 64 dependent memory round trips.
+// AIL / BIL: the A / B operand was read row-contiguous, so fragment f holds the strip's rows (cols) 2i + f.
+template <bool AIL, bool BIL>
+__device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2][2], int tm, int tn, int split,
+                                          int wm, int wn, int r, int h) {
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) {
+            const int col = tn * GEMM_BN + wn * 64 + (BIL ? 2 * r + fn : fn * 32 + r);
+            const bool colok = col < ep.cols;
+            const int colc = colok ? col : 0;
+            constexpr int RS = AIL ? 2 : 1;                                   // row step per MFMA row index
+            const int64_t row0 = (int64_t)tm * GEMM_BM + wm * 64 + (AIL ? fm : fm * 32) + RS * 4 * h;
+            if (mode == EPI_RAW) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e];
+                }
+            } else if (mode == EPI_BIAS_RELU) {
+                const float bv = ep.bias ? ep.bias[colc] : 0.f;
+                const float lo = ep.relu ? 0.f : -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[fm][fn][e] + bv, lo);
+                }
+            } else if (mode == EPI_MUL) {
+                float mv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    mv[e] = ep.mul[(row < ep.rows ? row : ep.rows - 1) * ep.ldmul + colc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e] * mv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
+                    if (colok && row < ep.rows) outp[row * ep.ld + col] = epi_apply(ep, acc[fm][fn][e], row, col);
+                }
+            }
+        }
+}
+
+__device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int m_fast, int& tm, int& tn) {
+    const unsigned v = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
+    if (m_fast) { tm = (int)(v % (unsigned)tiles_m); tn = (int)(v / (unsigned)tiles_m); }
+    else        { tn = (int)(v % (unsigned)tiles_n); tm = (int)(v / (unsigned)tiles_n); }
+}
+
+// implemented in gemm_f32.hip
+int launch_splitk_reduce(const char* name, const float* slabs, int nsplit, int64_t slab_stride, const EpiP& ep, hipStream_t st);
+int pick_splits(int64_t tiles, int ktiles);
+
+}  // namespace goalnet

@@ -28,7 +28,7 @@ def _chk(*ts):
             continue
         if not t.is_cuda:
             raise _lib.GoalnetError("expected a GPU tensor")
-        if t.dtype not in (F32, torch.float64, torch.uint8):
+        if t.dtype not in (F32, torch.float64, torch.uint8, torch.bfloat16):
             raise _lib.GoalnetError(f"unexpected dtype {t.dtype}")
 
 
@@ -156,6 +156,46 @@ def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
     check(lib().goalnet_conv3x3_wgrad(x.data_ptr(), _p(scale), _p(shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
                                       N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
     return dw
+
+
+BF16 = torch.bfloat16
+
+
+def cast_bf16(x, y):
+    _chk(x, y)
+    assert x.dtype == F32 and y.dtype == BF16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().goalnet_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _s()), "cast_bf16")
+    return y
+
+
+def bn_apply_bf16(x, scale, shift, y, C):
+    _chk(x, scale, shift, y)
+    assert x.dtype == F32 and y.dtype == BF16 and x.numel() == y.numel() and scale.numel() == C
+    check(lib().goalnet_bn_apply_bf16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _s()), "bn_apply_bf16")
+    return y
+
+
+def conv3x3_fwd_bf16(x, w, bias, relu, y, N, H, W, Cin, Cout):
+    _chk(x, w, bias, y)
+    assert x.dtype == BF16 and w.dtype == BF16 and y.dtype == F32
+    assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    check(lib().goalnet_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
+          "conv3x3_fwd_bf16")
+    return y
+
+
+def linear_fwd_bf16(x, w, bias, y, *, relu=False, dropmask=None, mult_out=None):
+    _chk(x, w, bias, y, dropmask, mult_out)
+    assert x.dtype == BF16 and w.dtype == BF16
+    M, K = x.shape
+    J = y.shape[1]
+    assert w.numel() == J * K and y.shape[0] == M
+    nbytes = lib().goalnet_linear_fwd_bf16_ws_bytes(M, K, J)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=x.device) if nbytes else None
+    check(lib().goalnet_linear_fwd_bf16(x.data_ptr(), _ld(x), w.data_ptr(), _p(bias), int(relu), _p(dropmask),
+                                        0 if dropmask is None else _ld(dropmask), y.data_ptr(), _ld(y), _p(mult_out),
+                                        0 if mult_out is None else _ld(mult_out), M, K, J, _p(ws), nbytes, _s()), "linear_fwd_bf16")
+    return y
 
 
 def linear_fwd(x, w, bias, y, *, relu=False, scale=None, shift=None, bnC=0, dropmask=None, mult_out=None, K=None):

@@ -100,6 +100,22 @@ size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
                           void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 
+/* ---- precision = "bf16" mode: the same contractions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate). Operands are bf16 copies produced by the two cast passes below; everything else stays fp32.
+ * The reference is fp32 (utils.py:37-47): this mode is an extension with its own tolerance (logits <= 1e-3). ---- */
+/* y_bf16[i] = bf16(x[i]); n % 8 == 0 */
+int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+/* y_bf16 = bf16(x * scale[c] + shift[c]), c = i mod C: the BatchNorm output utils.py:177/182/187, materialised in bf16 */
+int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);
+/* y = [relu](conv3x3(x_bf16 NHWC, w_bf16 OHWI) + bias), fp32 out; Cin % 64 == 0. Data gradient with flipped weights. */
+int goalnet_conv3x3_fwd_bf16(const void* x_bf16, const void* w_bf16, const float* bias, int relu, float* y,
+                             int N, int H, int W, int Cin, int Cout, void* stream);
+/* goalnet_linear_fwd on bf16 operands (x_bf16 [M][K] with leading dim ldx elements, w_bf16 [J][K]); K % 64 == 0 */
+size_t goalnet_linear_fwd_bf16_ws_bytes(int M, int64_t K, int J);
+int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, const float* bias, int relu,
+                            const float* dropmask, int64_t ldmask, float* y, int64_t ldy, float* mult_out, int64_t ldmult,
+                            int M, int64_t K, int J, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Linear layers (linear5, audbl.linear3, fusion.0/3/6/9).  utils.py:168-170, 211, 243-253 ---- */
 /* y[m][j] = act(sum_k xa[m][k] * w[j][k] + bias[j]) * dropmask[m][j]
  *   xa = x*scale[k % bnC] + shift[k % bnC] when scale != NULL (BatchNorm folded into the load);

@@ -32,6 +32,12 @@ def conv_case(name, h, w, cin, cout):
     dw = torch.empty(cout, 3, 3, cin, device=dev)
     t, ta = timeit(lambda: ops.conv3x3_wgrad(x, sc, sh, dy, dw, n, h, w, cin, cout))
     print(f"{name} wgrad : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    xb = x.to(torch.bfloat16); wb = wt.to(torch.bfloat16)
+    t, ta = timeit(lambda: ops.conv3x3_fwd_bf16(xb, wb, b, True, y, n, h, w, cin, cout))
+    print(f"{name} fwd bf16   : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    dyb = dy.to(torch.bfloat16); wfb = wtf.to(torch.bfloat16)
+    t, ta = timeit(lambda: ops.conv3x3_fwd_bf16(dyb, wfb, None, False, dx, n, h, w, cout, cin))
+    print(f"{name} dgrad bf16 : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
 
 def lin5_case(hw3):
     k = 512 * hw3
@@ -40,6 +46,9 @@ def lin5_case(hw3):
     y = torch.empty(n, 512, device=dev); fl = 2.0 * n * k * 512
     t, ta = timeit(lambda: ops.linear_fwd(x, w, b, y, relu=True, scale=sc, shift=sh, bnC=512))
     print(f"linear5 fwd   : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s   ({w.numel() * 4 / t / 1e6:.0f} GB/s weight stream)")
+    xb = x.to(torch.bfloat16); wb = w.to(torch.bfloat16)
+    t, ta = timeit(lambda: ops.linear_fwd_bf16(xb, wb, b, y, relu=True))
+    print(f"linear5 fwd bf16: {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s   ({wb.numel() * 2 / t / 1e6:.0f} GB/s weight stream)")
     dy = torch.randn(n, 512, device=dev); dx = torch.empty(n, k, device=dev)
     t, ta = timeit(lambda: ops.linear_bwd_dx(dy, w, dx))
     print(f"linear5 dX    : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")

@@ -333,3 +333,52 @@ def test_adam_three_steps_matches_torch_adam():
         opt.step()
         ops.adam_step(pg, g.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
         close(f"adam.step{step}", pg, p_ref.detach(), rtol=0.0, atol=2e-7)
+
+
+# ------------------------------------------------------------------------------------------------
+# precision = "bf16" engine. Products of bf16 values are exact in fp32 and accumulation is fp32, so against an
+# fp64 reference computed from the SAME bf16-rounded operands the kernels are as tight as the fp32 ones.
+# ------------------------------------------------------------------------------------------------
+def test_bf16_cast_passes_bit_exact():
+    x = rnd(3, 5, 7, 64, seed=50, lo=-3, hi=3)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(x.to(DEV), y)
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))                # round-to-nearest-even, as torch
+    sc = rnd(64, seed=51, lo=0.5, hi=1.5); sh = rnd(64, seed=52)
+    ops.bn_apply_bf16(x.to(DEV), sc.to(DEV), sh.to(DEV), y, 64)
+    want = torch.addcmul(sh, x, sc)                                   # fp32 fma, then one rounding to bf16
+    got = y.cpu().float()
+    ulp = (want.abs() * 2.0 ** -8).clamp_min(1e-30)
+    assert ((got - want).abs() <= ulp).all()
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [
+    (2, 7, 5, 64, 256, True, True),
+    (3, 13, 13, 64, 256, True, True),
+    (16, 11, 11, 256, 512, True, True),
+    (16, 11, 11, 512, 256, False, False),     # data-gradient form
+    (2, 13, 13, 256, 64, False, False),
+])
+def test_conv3x3_fwd_bf16(n, h, w, cin, cout, bias, relu):
+    x = rnd(n, h, w, cin, seed=53).to(torch.bfloat16)
+    wt = rnd(cout, 3, 3, cin, seed=54, lo=-0.05, hi=0.05).to(torch.bfloat16)
+    b = rnd(cout, seed=55) if bias else None
+    ref = F.conv2d(nchw(x.double()), wt.double().permute(0, 3, 1, 2), None if b is None else b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV)
+    ops.conv3x3_fwd_bf16(x.to(DEV), wt.to(DEV), None if b is None else b.to(DEV), relu, y, n, h, w, cin, cout)
+    close(f"conv3x3_fwd_bf16[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)
+
+
+@pytest.mark.parametrize("m,k,j", [(10, 41472, 512), (37, 640, 512), (130, 512, 256)])
+def test_linear_fwd_bf16(m, k, j):
+    x = rnd(m, k, seed=56).to(torch.bfloat16)
+    w = rnd(j, k, seed=57, lo=-0.05, hi=0.05).to(torch.bfloat16)
+    b = rnd(j, seed=58)
+    dm = (torch.rand(m, j, generator=torch.Generator().manual_seed(59)) >= 0.2).float() * 1.25
+    ref = F.relu(x.double() @ w.double().t() + b.double()) * dm.double()
+    y = torch.full((m, j), float("nan"), device=DEV)
+    mv = torch.empty(m, j, device=DEV)
+    ops.linear_fwd_bf16(x.to(DEV), w.to(DEV), b.to(DEV), y, relu=True, dropmask=dm.to(DEV), mult_out=mv)
+    close(f"linear_fwd_bf16[{m}x{k}->{j}]", y, ref, rtol=3e-6)
