@@ -42,6 +42,13 @@ PROTOTYPES = {
     "goalnet_conv3x3_fwd_bf16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_linear_fwd_bf16_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "goalnet_linear_fwd_bf16": (c_int, [P, c_int64, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
+    "goalnet_bf16_padded_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "goalnet_to_bf16_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_linear_bwd_dx_bf16": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
+    "goalnet_linear_bwd_dw_bf16": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int64, c_int, P]),
     "goalnet_linear_fwd_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "goalnet_linear_fwd": (c_int, [P, c_int64, P, P, c_int, P, P, c_int, P, c_int64, P, c_int64, P, c_int64,
                                    c_int, c_int64, c_int, P, c_size_t, P]),

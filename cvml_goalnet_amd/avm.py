@@ -322,6 +322,16 @@ class AVM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # forward / backward on device tensors
     # ------------------------------------------------------------------------------------------
+    def _padbuf(self, key, n, h, w, c):
+        """Cached zero-padded bf16 activation buffer (borders/guards zeroed once, interior rewritten every step)."""
+        k = (key, n, h, w, c)
+        if not hasattr(self, "_padbufs"):
+            self._padbufs, self._padgen = {}, {}
+        if k not in self._padbufs:
+            self._padbufs[k] = ops.padded_bf16_alloc(n, h, w, c, self._device)
+        self._padgen[key] = self._padgen.get(key, 0) + 1      # backward checks that its saved operand was not overwritten
+        return self._padbufs[k][1]
+
     def _timed(self, label, flops, fn, *args):
         """Run one kernel launch; when bench.py asked for it, bracket it with HIP events on the launching stream."""
         if self.kernel_events is None:
@@ -383,22 +393,20 @@ class AVM(nn.Module):
         bf = self.precision == "bf16"
         BF16 = torch.bfloat16
         if bf:
-            xh1 = ops.bn_apply_bf16(p1, st1[2], st1[3], torch.empty(p1.shape, dtype=BF16, device=dev), 64)
+            xh1 = ops.to_bf16_padded(p1, st1[2], st1[3], self._padbuf("x1" if save else "x1e", n, hp1, wp1, 64), n, hp1, wp1, 64)
             w2b = ops.cast_bf16(P("visbl.conv2.weight"), torch.empty(256 * 9 * 64, dtype=BF16, device=dev))
-            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16,
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16p,
                         xh1, w2b, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
-            del xh1
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
         y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
         if bf:
-            xh2 = ops.bn_apply_bf16(p2, st2[2], st2[3], torch.empty(p2.shape, dtype=BF16, device=dev), 256)
+            xh2 = ops.to_bf16_padded(p2, st2[2], st2[3], self._padbuf("x2" if save else "x2e", n, hp2, wp2, 256), n, hp2, wp2, 256)
             w3b = ops.cast_bf16(P("visbl.conv3.weight"), torch.empty(512 * 9 * 256, dtype=BF16, device=dev))
-            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16,
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16p,
                         xh2, w3b, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
-            del xh2
         else:
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
@@ -414,6 +422,8 @@ class AVM(nn.Module):
             w5b = ops.cast_bf16(P("visbl.linear5.weight"), torch.empty(512 * k5, dtype=BF16, device=dev))
             ops.linear_fwd_bf16(xh3.view(n, k5), w5b, P("visbl.linear5.bias"), cat[:, voff:], relu=True,
                                 dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+            if save:
+                ctx.update(xh1=xh1, xh2=xh2, xh3=xh3, w5b=w5b, padgen=(self._padgen["x1"], self._padgen["x2"]))
             del xh3, w5b
         else:
             ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
@@ -509,27 +519,41 @@ class AVM(nn.Module):
         k5 = 512 * hp3 * wp3
         p3f = ctx["p3"].view(n, k5)
         st3 = ctx["st3"]
-        ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512)
-        if on_bucket:
-            on_bucket(1)
+        bf = self.precision == "bf16"
         dbn3 = torch.empty(n, hp3, wp3, 512, dtype=F32, device=dev)
-        ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
+        if bf and ctx["padgen"] != (self._padgen["x1"], self._padgen["x2"]):
+            raise RuntimeError("precision='bf16': a second training-mode forward overwrote the saved bf16 operands before "
+                               "backward ran; call backward after each forward (as the reference's loop does)")
+        if bf:
+            dz5b = ops.cast_bf16(dz5.contiguous(), torch.empty(n, 512, dtype=torch.bfloat16, device=dev))
+            ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight"))
+            if on_bucket:
+                on_bucket(1)
+            ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
+        else:
+            ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512)
+            if on_bucket:
+                on_bucket(1)
+            ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
 
         # block 3 (utils.py:184-187)
         dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
         del dbn3
         st2 = ctx["st2"]
-        self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
-                    ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+        if bf:
+            dyp3 = ops.to_bf16_padded(dy3, None, None, self._padbuf("dy3", n, hp2, wp2, 512), n, hp2, wp2, 512)
+            self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
+                        ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+        else:
+            self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
+                        ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         dbn2 = torch.empty(n, hp2, wp2, 256, dtype=F32, device=dev)
         if self.precision == "bf16":
-            dyb = ops.cast_bf16(dy3, torch.empty(dy3.shape, dtype=torch.bfloat16, device=dev))
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
-            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16,
-                        dyb, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
-            del dyb
+            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
+                        dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
         else:
             self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
                         dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
@@ -539,17 +563,20 @@ class AVM(nn.Module):
         dy2 = self._block_bwd(dbn2, ctx, 2, n, hp1, wp1, 256)
         del dbn2
         st1 = ctx["st1"]
-        self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
-                    ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+        if bf:
+            dyp2 = ops.to_bf16_padded(dy2, None, None, self._padbuf("dy2", n, hp1, wp1, 256), n, hp1, wp1, 256)
+            self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
+                        ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+        else:
+            self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
+                        ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
         wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
         if self.precision == "bf16":
-            dyb = ops.cast_bf16(dy2, torch.empty(dy2.shape, dtype=torch.bfloat16, device=dev))
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
-            self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_bf16,
-                        dyb, wtb, None, False, dbn1, n, hp1, wp1, 256, 64)
-            del dyb
+            self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_bf16p,
+                        dyp2, wtb, None, False, dbn1, n, hp1, wp1, 256, 64)
         else:
             self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
                         dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)

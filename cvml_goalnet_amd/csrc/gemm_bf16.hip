@@ -50,6 +50,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_dst, u
 // K-contiguous bf16 matrix X[rows][K] (leading dim ld elements).
 struct KCLoaderH {
     struct P { const __hip_bfloat16* x; int64_t ld; int rows; };
+    static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[4];
     int wave;
@@ -75,6 +76,7 @@ struct KCLoaderH {
 // The resource starts W+1 pixels in front of the tile; padding taps are out-of-range voffsets -> zeros land in LDS.
 struct ConvALoaderH {
     struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; };
+    static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[4], mask[4];
     int W, C, wave;
@@ -116,15 +118,161 @@ struct ConvALoaderH {
     }
 };
 
+// ---- row-contiguous ("transposed") operands: the reduction index is the slow index in memory -------------------------
+// LDS image [64 k-rows][128 cols] bf16 = 256-B rows, filled by DMA (1 KB = 4 k-rows per wave-instruction) and read with
+// ds_read_b64_tr_b16 (each 16-lane group fetches a 4 x 16 block and receives it column-major = 4 consecutive k of one
+// column per lane; two reads = the 8 k-values of an MFMA operand). The sixteen 16-B chunks of a row are XOR-swizzled
+// by 2 * (krow & 7) (on the DMA source address), and a 32-row MFMA fragment takes the 16-column units {u, u + 4}: the two
+// groups of a 32-lane half then read disjoint 128-B halves of the bank row -> conflict-free (layout derived from the
+// bank rule of MI355X_MICROARCH.md §LDS; semantics of the transposed read probed in scripts/probe/tr_probe.hip).
+constexpr int TROWB = 256;
+__device__ __forceinline__ int tr_chunk(int krow, int chunk) { return chunk ^ (2 * (krow & 7)); }
+
+// plain matrix X[kred][cols] (leading dim ld elements); re-based every K-tile, rows past kred / cols past `cols` read 0
+struct MCLoaderH {
+    struct P { const __hip_bfloat16* x; int64_t ld; int cols; int kred; };
+    static constexpr bool TR = true;
+    const __hip_bfloat16* x;
+    int64_t ld;
+    int kred, wave;
+    unsigned voff[4];
+    __device__ MCLoaderH(const P& p, int col0, int tid) {
+        x = p.x; ld = p.ld; kred = p.kred;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (wave * 4 + i) * 4 + (lane >> 4);
+            const int col = col0 + tr_chunk(kr, lane & 15) * 8;
+            voff[i] = col < p.cols ? (unsigned)(((int64_t)kr * p.ld + col) * 2) : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kt, char* l) const {
+        const int kbase = kt * BKH;
+        const int nk = kred - kbase < BKH ? kred - kbase : BKH;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (int64_t)kbase * ld, clamp_u32((int64_t)nk * ld * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rx, l + (wave * 4 + i) * 4 * TROWB, voff[i], 0);
+    }
+};
+
+// B operand of the conv weight gradient on the zero-PADDED pixel grid: B(col = (tap, ci), k = pm) = xpad[pm + shift(tap)][ci].
+// With a zero border around every frame the tap shift is a constant pixel offset for the whole reduction (no per-pixel
+// validity), and pad pixels contribute nothing because dy_pad is zero there. `x` points at padded pixel 0 of a buffer
+// that has G = W+3 zero guard pixels (padded width W+2) in front and behind.
+struct ConvWgradBLoaderH {
+    struct P { const __hip_bfloat16* x; int Wp2, C; int64_t Mp; };     // Wp2 = W + 2, Mp = N*(H+2)*(W+2)
+    static constexpr bool TR = true;
+    const __hip_bfloat16* x;
+    int C, G, wave;
+    unsigned voff[4];
+    __device__ ConvWgradBLoaderH(const P& p, int col0, int tid) {
+        x = p.x; C = p.C; G = p.Wp2 + 1;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kr = (wave * 4 + i) * 4 + (lane >> 4);
+            const int col = col0 + tr_chunk(kr, lane & 15) * 8;
+            if (col < 9 * p.C) {
+                const int tap = col / p.C, ci = col - tap * p.C;
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                voff[i] = (unsigned)(((kr + kh * p.Wp2 + kw) * p.C + ci) * 2);       // relative to pixel (kbase - G)
+            } else {
+                voff[i] = OOB;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int kt, char* l) const {
+        const int64_t kbase = (int64_t)kt * BKH;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (kbase - G) * C, (uint32_t)((BKH + 2 * G) * C * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rx, l + (wave * 4 + i) * 4 * TROWB, voff[i], 0);
+    }
+};
+
+// im2col of a zero-padded bf16 NHWC tensor (same buffer convention as above): row m = (n,h,w) of the OUTPUT grid,
+// k = (kh,kw,ci); no validity masks at all.
+struct ConvAPadLoaderH {
+    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; };
+    static constexpr bool TR = false;
+    __amdgpu_buffer_rsrc_t rx;
+    unsigned voff[4];
+    int Wp2, C, wave;
+    __device__ ConvAPadLoaderH(const P& p, int row0, int tid) {
+        Wp2 = p.W + 2; C = p.C;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+        const int hw = p.H * p.W;
+        const int n0 = row0 / hw, r0 = row0 - n0 * hw, h0 = r0 / p.W, w0 = r0 - h0 * p.W;
+        const int64_t pm0 = ((int64_t)n0 * (p.H + 2) + h0 + 1) * Wp2 + w0 + 1;      // padded index of the tile's first pixel
+        const int G = Wp2 + 1;
+        // a tile of 128 consecutive output pixels spans < 128 + 2 * (rows crossed + frames crossed * (W+2)) padded pixels
+        rx = make_rsrc(p.x + (pm0 - G) * p.C, (uint32_t)((BM + 2 * (BM / p.W + 2) + 4 * Wp2 + 2 * G) * p.C * 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = (wave * 4 + i) * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((rl >> 1) & 7);
+            const int64_t m = (int64_t)row0 + rl;
+            if (m < p.M) {
+                const int n = (int)(m / hw), rr = (int)(m - (int64_t)n * hw), h = rr / p.W, w = rr - h * p.W;
+                const int64_t pm = ((int64_t)n * (p.H + 2) + h + 1) * Wp2 + w + 1;
+                voff[i] = (unsigned)(((pm - pm0) * p.C + lc * 8) * 2);
+            } else {
+                voff[i] = OOB;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int kt, char* l) const {
+        const int k = kt * BKH;
+        const int tap = k / C;
+        const int ci = k - tap * C;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const unsigned s0 = (unsigned)(((kh * Wp2 + kw) * C + ci) * 2);      // (kh-1, kw-1) shift + the G-pixel lead
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rx, l + (wave * 4 + i) * 8 * ROWB, voff[i], s0);
+    }
+};
+
 // ---- the MFMA tile --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void compute_tile_h(const char* la, const char* lb, f32x16 (&acc)[2][2], int wm, int wn, int r, int h) {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// tile row (or column) of MFMA index i (0..31) of fragment f of strip s for the two operand forms
+template <bool TR>
+__device__ __forceinline__ int frag_index(int s, int f, int i) {
+    return TR ? 16 * (2 * s + f + 4 * (i >> 4)) + (i & 15) : s * 64 + f * 32 + i;
+}
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag_h(const char* l, int s, int f, int ks, int lane) {
+    if (!TR) {
+        const int r = lane & 31, h = lane >> 5;
+        return *reinterpret_cast<const bf16x8*>(l + kc_boff(s * 64 + f * 32 + r, 2 * ks + h));
+    } else {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int unit = 2 * s + f + 4 * (g & 1);                    // 16-column unit this 16-lane group transposes
+        const int chunk = 2 * unit + (p >> 1);
+        s16x4 v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kr = 16 * ks + 8 * (g >> 1) + 4 * t + q;
+            const char* a = l + kr * TROWB + tr_chunk(kr, chunk) * 16 + (p & 1) * 8;
+            v[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
+        }
+        return bf16x8{v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+    }
+}
+
+template <bool ATR, bool BTR>
+__device__ __forceinline__ void compute_tile_h(const char* la, const char* lb, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         bf16x8 a[2], b[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            a[f] = *reinterpret_cast<const bf16x8*>(la + kc_boff(wm * 64 + f * 32 + r, 2 * ks + h));
-            b[f] = *reinterpret_cast<const bf16x8*>(lb + kc_boff(wn * 64 + f * 32 + r, 2 * ks + h));
+            a[f] = read_frag_h<ATR>(la, wm, f, ks, lane);
+            b[f] = read_frag_h<BTR>(lb, wn, f, ks, lane);
         }
 #pragma unroll
         for (int fm = 0; fm < 2; ++fm)
@@ -132,6 +280,43 @@ __device__ __forceinline__ void compute_tile_h(const char* la, const char* lb, f
             for (int fn = 0; fn < 2; ++fn)
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
     }
+}
+
+// epilogue for either operand form (gemm_common.h's store_acc covers the K-contiguous/K-contiguous case)
+template <bool ATR, bool BTR>
+__device__ __forceinline__ void store_acc_h(const EpiP& ep, const f32x16 (&acc)[2][2], int tm, int tn, int split,
+                                            int wm, int wn, int lane) {
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 2; ++fn) {
+            const int col = tn * BN + frag_index<BTR>(wn, fn, r);
+            const bool colok = col < ep.cols;
+            const int colc = colok ? col : 0;
+            float mv[16];
+            if (mode == EPI_MUL) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = (int64_t)tm * BM + frag_index<ATR>(wm, fm, (e & 3) + 8 * (e >> 2) + 4 * h);
+                    mv[e] = ep.mul[(row < ep.rows ? row : ep.rows - 1) * ep.ldmul + colc];
+                }
+            }
+            const float bv = (mode == EPI_BIAS_RELU && ep.bias) ? ep.bias[colc] : 0.f;
+            const float lo = (mode == EPI_BIAS_RELU && ep.relu) ? 0.f : -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = (int64_t)tm * BM + frag_index<ATR>(wm, fm, (e & 3) + 8 * (e >> 2) + 4 * h);
+                if (!(colok && row < ep.rows)) continue;
+                const float v = acc[fm][fn][e];
+                if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
+                else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v + bv, lo);
+                else if (mode == EPI_MUL) outp[row * ep.ld + col] = v * mv[e];
+                else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
+            }
+        }
 }
 
 template <class AL, class BL>
@@ -151,7 +336,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -173,11 +357,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
             al.issue(kt + 1, lds[cur ^ 1][0]);
             bl.issue(kt + 1, lds[cur ^ 1][1]);
         }
-        compute_tile_h(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        compute_tile_h<AL::TR, BL::TR>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA data has landed before anyone passes the barrier
         __syncthreads();
     }
-    store_acc<false, false>(ep, acc, tm, tn, split, wm, wn, r, h);
+    store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, split, wm, wn, lane);
 }
 
 template <class AL, class BL>
@@ -219,6 +403,31 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const float* __restr
         const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
         reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y)), pack2(fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w)),
                                                pack2(fmaf(b.x, s1.x, t1.x), fmaf(b.y, s1.y, t1.y)), pack2(fmaf(b.z, s1.z, t1.z), fmaf(b.w, s1.w, t1.w))};
+    }
+}
+
+// x fp32 [N][H][W][C] -> bf16 zero-padded [N][H+2][W+2][C] (interior only; the caller zeroed the buffer once),
+// optional per-channel affine. One thread = 8 channels of one pixel.
+__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
+                                                            int64_t n8, int H, int W, int C) {
+    const int c8n = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8;
+        const int64_t pix = i / c8n;
+        const int w = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int h = (int)(t % H);
+        const int64_t n = t / H;
+        const int64_t pm = (n * (H + 2) + h + 1) * (W + 2) + w + 1;
+        float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        if (scale) {
+            const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
+            a = make_float4(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y), fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w));
+            b = make_float4(fmaf(b.x, s1.x, t1.x), fmaf(b.y, s1.y, t1.y), fmaf(b.z, s1.z, t1.z), fmaf(b.w, s1.w, t1.w));
+        }
+        *reinterpret_cast<u32x4*>(y + pm * C + c) = u32x4{pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w)};
     }
 }
 
@@ -299,6 +508,108 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
     const int rc = launch_gemm_h<KCLoaderH, KCLoaderH>("linear_fwd_bf16", ap, bp, ep, M, J, (int)(K / BKH), nsplit, 0, st);
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("linear_fwd_bf16.reduce", (const float*)ws, nsplit, (int64_t)M * J, efinal, st);
+}
+
+/* ---- zero-padded bf16 tensors: [N][H+2][W+2][C] with G = W+3 zero pixels in front of padded pixel 0 and G + 64 behind.
+ * The pointer passed around is the address of padded pixel 0; goalnet_bf16_padded_layout gives the allocation. ---- */
+int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems, int64_t* offset_elems) {
+    GN_REQUIRE(total_elems && offset_elems, GOALNET_E_NULL, "bf16_padded_layout: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, GOALNET_E_SHAPE, "bf16_padded_layout: non-positive dim");
+    const int64_t G = W + 3, Mp = (int64_t)N * (H + 2) * (W + 2);
+    *offset_elems = G * C;
+    *total_elems = (G + Mp + G + 64) * C;
+    return 0;
+}
+
+int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream) {
+    GN_REQUIRE(x && y_pad, GOALNET_E_NULL, "to_bf16_padded: null pointer");
+    GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "to_bf16_padded: scale/shift must both be set or both NULL");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, GOALNET_E_SHAPE, "to_bf16_padded: bad dims (C %% 8)");
+    GN_REQUIRE(aligned16(x) && aligned16(y_pad) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "to_bf16_padded: alignment");
+    const int64_t n8 = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(to_bf16_padded_kernel, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       (__hip_bfloat16*)y_pad, n8, H, W, C);
+    GN_LAUNCH_CHECK("to_bf16_padded");
+    return 0;
+}
+
+int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
+                              int N, int H, int W, int Cin, int Cout, void* stream) {
+    GN_REQUIRE(x_pad && w_bf16 && y, GOALNET_E_NULL, "conv3x3_fwd_bf16p: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: non-positive dim");
+    GN_REQUIRE(Cin % BKH == 0 && Cout % 4 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: Cin %% 64, Cout %% 4");
+    GN_REQUIRE(aligned16(x_pad) && aligned16(w_bf16) && aligned16(y), GOALNET_E_ALIGN, "conv3x3_fwd_bf16p: alignment");
+    const int64_t M = (int64_t)N * H * W;
+    GN_REQUIRE((int64_t)N * (H + 2) * (W + 2) < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: too many pixels");
+    ConvAPadLoaderH::P ap{(const __hip_bfloat16*)x_pad, H, W, Cin, M};
+    KCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, (int64_t)9 * Cin, Cout};
+    EpiP ep{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
+    return launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, 1, 0, (hipStream_t)stream);
+}
+
+static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {
+    const int64_t tiles = (int64_t)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
+    const int ktiles = (int)((Mp + BKH - 1) / BKH);
+    int64_t s = (2048 + tiles - 1) / tiles;
+    const int64_t smax = ktiles / 16 > 1 ? ktiles / 16 : 1;
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    const int kps = (int)((ktiles + s - 1) / s);
+    return (ktiles + kps - 1) / kps;
+}
+
+size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    return (size_t)wgrad_splits_h(Mp, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
+}
+
+/* dw[Cout][3][3][Cin] (fp32) = sum over the padded pixel grid of dy_pad[pm][co] * x_pad[pm + shift(tap)][ci] */
+int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
+                               int N, int H, int W, int Cin, int Cout, void* stream) {
+    GN_REQUIRE(x_pad && dy_pad && dw && ws, GOALNET_E_NULL, "conv3x3_wgrad_bf16: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE,
+               "conv3x3_wgrad_bf16: channels must be positive multiples of 8");
+    GN_REQUIRE(aligned16(x_pad) && aligned16(dy_pad) && aligned16(dw) && aligned16(ws), GOALNET_E_ALIGN, "conv3x3_wgrad_bf16: alignment");
+    const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
+    GN_REQUIRE(Mp < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_wgrad_bf16: too many pixels");
+    GN_REQUIRE(ws_bytes >= goalnet_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout), GOALNET_E_WORKSPACE, "conv3x3_wgrad_bf16: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nsplit = wgrad_splits_h(Mp, Cin, Cout);
+    const int ktiles = (int)((Mp + BKH - 1) / BKH);
+    const int64_t slab = (int64_t)Cout * 9 * Cin;
+    MCLoaderH::P ap{(const __hip_bfloat16*)dy_pad, Cout, Cout, (int)Mp};
+    ConvWgradBLoaderH::P bp{(const __hip_bfloat16*)x_pad, W + 2, Cin, Mp};
+    EpiP ep{EPI_RAW, (float*)ws, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
+    const int rc = launch_gemm_h<MCLoaderH, ConvWgradBLoaderH>("conv3x3_wgrad_bf16", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
+    if (rc) return rc;
+    EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    return launch_splitk_reduce("conv3x3_wgrad_bf16.reduce", (const float*)ws, nsplit, slab, er, st);
+}
+
+/* dx[m][k] = (sum_j dy_bf16[m][j] * w_bf16[j][k]) * mult[m][k]   (fp32 out, mult nullable); J % 64 == 0 */
+int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
+                               float* dx, int64_t lddx, int M, int64_t K, int J, void* stream) {
+    GN_REQUIRE(dy_bf16 && w_bf16 && dx, GOALNET_E_NULL, "linear_bwd_dx_bf16: null pointer");
+    GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: bad dims");
+    GN_REQUIRE(J % BKH == 0 && K % 8 == 0 && lddy % 8 == 0 && lddx % 4 == 0, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: J %% 64, K %% 8");
+    GN_REQUIRE(aligned16(dy_bf16) && aligned16(w_bf16) && aligned16(dx), GOALNET_E_ALIGN, "linear_bwd_dx_bf16: alignment");
+    KCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, M};
+    MCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, K, (int)K, J};
+    EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};
+    return launch_gemm_h<KCLoaderH, MCLoaderH>("linear_bwd_dx_bf16", ap, bp, ep, M, K, J / BKH, 1, 1, (hipStream_t)stream);
+}
+
+/* dw[j][k] = sum_m dy_bf16[m][j] * x_bf16[m][k]   (fp32 out) */
+int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_bf16, int64_t ldx, float* dw,
+                               int M, int64_t K, int J, void* stream) {
+    GN_REQUIRE(dy_bf16 && x_bf16 && dw, GOALNET_E_NULL, "linear_bwd_dw_bf16: null pointer");
+    GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: bad dims");
+    GN_REQUIRE(J % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: J, K, lds %% 8");
+    GN_REQUIRE(aligned16(dy_bf16) && aligned16(x_bf16) && aligned16(dw), GOALNET_E_ALIGN, "linear_bwd_dw_bf16: alignment");
+    MCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, J, M};
+    MCLoaderH::P bp{(const __hip_bfloat16*)x_bf16, ldx, (int)K, M};
+    EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    return launch_gemm_h<MCLoaderH, MCLoaderH>("linear_bwd_dw_bf16", ap, bp, ep, J, K, (M + BKH - 1) / BKH, 1, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -184,6 +184,62 @@ def conv3x3_fwd_bf16(x, w, bias, relu, y, N, H, W, Cin, Cout):
     return y
 
 
+def padded_bf16_alloc(N, H, W, C, device):
+    """Zeroed bf16 buffer for a padded [N][H+2][W+2][C] tensor with its guard bands; returns (buffer, view at padded pixel 0)."""
+    import ctypes as _ct
+    tot, off = _ct.c_int64(), _ct.c_int64()
+    check(lib().goalnet_bf16_padded_layout(N, H, W, C, _ct.byref(tot), _ct.byref(off)), "bf16_padded_layout")
+    buf = torch.zeros(tot.value, dtype=BF16, device=device)
+    return buf, buf[off.value:]
+
+
+def to_bf16_padded(x, scale, shift, ypad, N, H, W, C):
+    _chk(x, scale, shift, ypad)
+    assert x.dtype == F32 and ypad.dtype == BF16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
+    check(lib().goalnet_to_bf16_padded(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _s()), "to_bf16_padded")
+    return ypad
+
+
+def conv3x3_fwd_bf16p(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
+    _chk(xpad, w, bias, y)
+    assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == F32
+    assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    check(lib().goalnet_conv3x3_fwd_bf16p(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
+          "conv3x3_fwd_bf16p")
+    return y
+
+
+def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
+    _chk(xpad, dypad, dw)
+    assert xpad.dtype == BF16 and dypad.dtype == BF16 and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin
+    nbytes = lib().goalnet_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
+    check(lib().goalnet_conv3x3_wgrad_bf16(xpad.data_ptr(), dypad.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+                                           N, H, W, Cin, Cout, _s()), "conv3x3_wgrad_bf16")
+    return dw
+
+
+def linear_bwd_dx_bf16(dy, w, dx, mult=None):
+    _chk(dy, w, dx, mult)
+    assert dy.dtype == BF16 and w.dtype == BF16 and dx.dtype == F32
+    M, J = dy.shape
+    K = dx.shape[1]
+    assert w.numel() == J * K and dx.shape[0] == M
+    check(lib().goalnet_linear_bwd_dx_bf16(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
+                                           dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_bf16")
+    return dx
+
+
+def linear_bwd_dw_bf16(dy, x, dw):
+    _chk(dy, x, dw)
+    assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32
+    M, J = dy.shape
+    K = x.shape[1]
+    assert dw.numel() == J * K and x.shape[0] == M
+    check(lib().goalnet_linear_bwd_dw_bf16(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), dw.data_ptr(), M, K, J, _s()), "linear_bwd_dw_bf16")
+    return dw
+
+
 def linear_fwd_bf16(x, w, bias, y, *, relu=False, dropmask=None, mult_out=None):
     _chk(x, w, bias, y, dropmask, mult_out)
     assert x.dtype == BF16 and w.dtype == BF16

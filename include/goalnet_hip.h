@@ -116,6 +116,22 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
                             const float* dropmask, int64_t ldmask, float* y, int64_t ldy, float* mult_out, int64_t ldmult,
                             int M, int64_t K, int J, void* ws, size_t ws_bytes, void* stream);
 
+/* zero-padded bf16 activations [N][H+2][W+2][C]: with a zero border the 3x3 taps are constant pixel shifts (no masks),
+ * which is what lets the weight gradient run as a plain GEMM over the padded pixel grid. The buffer has W+3 zero
+ * guard pixels in front of padded pixel 0 and W+3+64 behind; `*_pad` arguments are the address of padded pixel 0 and
+ * the caller zeroes the whole buffer once (only interior pixels are ever written). */
+int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems, int64_t* offset_elems);
+int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);
+int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
+                              int N, int H, int W, int Cin, int Cout, void* stream);
+size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
+                               int N, int H, int W, int Cin, int Cout, void* stream);
+int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
+                               float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
+int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_bf16, int64_t ldx, float* dw,
+                               int M, int64_t K, int J, void* stream);
+
 /* ---- Linear layers (linear5, audbl.linear3, fusion.0/3/6/9).  utils.py:168-170, 211, 243-253 ---- */
 /* y[m][j] = act(sum_k xa[m][k] * w[j][k] + bias[j]) * dropmask[m][j]
  *   xa = x*scale[k % bnC] + shift[k % bnC] when scale != NULL (BatchNorm folded into the load);

@@ -35,6 +35,14 @@ def conv_case(name, h, w, cin, cout):
     xb = x.to(torch.bfloat16); wb = wt.to(torch.bfloat16)
     t, ta = timeit(lambda: ops.conv3x3_fwd_bf16(xb, wb, b, True, y, n, h, w, cin, cout))
     print(f"{name} fwd bf16   : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    bx, xp = ops.padded_bf16_alloc(n, h, w, cin, dev); ops.to_bf16_padded(x, sc, sh, xp, n, h, w, cin)
+    bd, dyp = ops.padded_bf16_alloc(n, h, w, cout, dev); ops.to_bf16_padded(dy, None, None, dyp, n, h, w, cout)
+    t, ta = timeit(lambda: ops.conv3x3_fwd_bf16p(xp, wb, b, True, y, n, h, w, cin, cout))
+    print(f"{name} fwd bf16p  : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    t, ta = timeit(lambda: ops.conv3x3_wgrad_bf16(xp, dyp, dw, n, h, w, cin, cout))
+    print(f"{name} wgrad bf16 : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
+    t, ta = timeit(lambda: ops.to_bf16_padded(x, sc, sh, xp, n, h, w, cin))
+    print(f"{name} to_bf16_padded(x): {t:8.3f} ms  {(x.numel() * 6) / t / 1e6:7.0f} GB/s")
     dyb = dy.to(torch.bfloat16); wfb = wtf.to(torch.bfloat16)
     t, ta = timeit(lambda: ops.conv3x3_fwd_bf16(dyb, wfb, None, False, dx, n, h, w, cout, cin))
     print(f"{name} dgrad bf16 : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (avg {fl / ta / 1e9:.1f})")
@@ -50,6 +58,13 @@ def lin5_case(hw3):
     t, ta = timeit(lambda: ops.linear_fwd_bf16(xb, wb, b, y, relu=True))
     print(f"linear5 fwd bf16: {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s   ({wb.numel() * 2 / t / 1e6:.0f} GB/s weight stream)")
     dy = torch.randn(n, 512, device=dev); dx = torch.empty(n, k, device=dev)
+    dyb = dy.to(torch.bfloat16)
+    t, ta = timeit(lambda: ops.linear_bwd_dx_bf16(dyb, wb, dx))
+    print(f"linear5 dX bf16 : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
+    dwb = torch.empty(512, k, device=dev)
+    t, ta = timeit(lambda: ops.linear_bwd_dw_bf16(dyb, xb, dwb))
+    print(f"linear5 dW bf16 : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
+    del dwb
     t, ta = timeit(lambda: ops.linear_bwd_dx(dy, w, dx))
     print(f"linear5 dX    : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
     dw = torch.empty(512, k, device=dev)

@@ -19,7 +19,7 @@ def short(name):
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)))
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)), key=os.path.getmtime)
     return fs[-1] if fs else None
 
 
@@ -35,7 +35,7 @@ if f:
     with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats — bench.py ({tag})\n\n")
         o.write("Command (on the MI355X box, scripts/profile_bench.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- "
-                "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (3 train steps in the trace: 1 warm-up + 2 timed).\n\n")
+                "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --dtype <see bench line>` (3 train steps in the trace: 1 warm-up + 2 timed).\n\n")
         if bench:
             o.write(f"bench line of the same run: value = {bench['value']:.2f} clips/s, {bench['ms_per_step']:.1f} ms/step; "
                     f"roofline: {json.dumps(bench.get('roofline'))}\n\n")
@@ -70,11 +70,13 @@ if agg:
             if b * 1024 < 1e6:
                 continue
             o.write(f"| `{k}` | {n} | {fe:.0f} | {wr:.0f} | {b * 1024 / 1e9:.3f} |\n")
-    key = next((k for k in agg if k.startswith("gemm_f32_kernel<ConvALoader<true>")), None)
-    if key:
+    for dt, prefix in (("f32", "gemm_f32_kernel<ConvALoader<true>"), ("bf16", "gemm_bf16_kernel<ConvAPadLoaderH")):
+        key = next((k for k in agg if k.startswith(prefix)), None)
+        if not key:
+            continue
         v = agg[key]
         fe = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]); wr = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
         json.dump({"kernel": key, "launches": len(v["FETCH_SIZE"]), "fetch_size_kib_avg": fe, "write_size_kib_avg": wr,
                    "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "source": f"profiles/{tag}_traffic.md"},
-                  open(os.path.join(out, "conv_fwd_traffic.json"), "w"), indent=1)
+                  open(os.path.join(out, f"conv_fwd_traffic_{dt}.json"), "w"), indent=1)
     print("wrote", f"{tag}_traffic.md")

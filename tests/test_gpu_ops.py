@@ -382,3 +382,68 @@ def test_linear_fwd_bf16(m, k, j):
     mv = torch.empty(m, j, device=DEV)
     ops.linear_fwd_bf16(x.to(DEV), w.to(DEV), b.to(DEV), y, relu=True, dropmask=dm.to(DEV), mult_out=mv)
     close(f"linear_fwd_bf16[{m}x{k}->{j}]", y, ref, rtol=3e-6)
+
+
+def _padded(x_nhwc_f32, sc=None, sh=None):
+    n, h, w, c = x_nhwc_f32.shape
+    buf, view = ops.padded_bf16_alloc(n, h, w, c, DEV)
+    ops.to_bf16_padded(x_nhwc_f32.to(DEV), None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), view, n, h, w, c)
+    return buf, view
+
+
+def test_to_bf16_padded_layout_exact():
+    x = rnd(2, 5, 7, 64, seed=60)
+    sc = rnd(64, seed=61, lo=0.5, hi=1.5); sh = rnd(64, seed=62)
+    buf, view = _padded(x, sc, sh)
+    n, h, w, c = x.shape
+    got = view[: n * (h + 2) * (w + 2) * c].view(n, h + 2, w + 2, c).cpu().float()
+    want = torch.zeros(n, h + 2, w + 2, c)
+    want[:, 1:-1, 1:-1, :] = torch.addcmul(sh, x, sc).to(torch.bfloat16).float()
+    assert torch.equal(got, want)
+    assert float(buf.float().abs().sum()) == float(want.abs().sum())       # guard bands stay zero
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [
+    (2, 7, 5, 64, 256, True, True), (3, 13, 13, 64, 256, True, True), (16, 11, 11, 256, 512, True, True),
+    (16, 11, 11, 512, 256, False, False), (2, 13, 13, 256, 64, False, False),
+])
+def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu):
+    x = rnd(n, h, w, cin, seed=63)
+    wt = rnd(cout, 3, 3, cin, seed=64, lo=-0.05, hi=0.05).to(torch.bfloat16)
+    b = rnd(cout, seed=65) if bias else None
+    _, xp = _padded(x)
+    ref = F.conv2d(nchw(x.to(torch.bfloat16).double()), wt.double().permute(0, 3, 1, 2), None if b is None else b.double(), padding=1)
+    if relu:
+        ref = F.relu(ref)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV)
+    ops.conv3x3_fwd_bf16p(xp, wt.to(DEV), None if b is None else b.to(DEV), relu, y, n, h, w, cin, cout)
+    close(f"conv3x3_fwd_bf16p[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 7, 5, 64, 256), (3, 13, 13, 64, 256), (16, 11, 11, 256, 512), (5, 9, 6, 64, 128)])
+def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
+    x = rnd(n, h, w, cin, seed=66)
+    dy = rnd(n, h, w, cout, seed=67)
+    _, xp = _padded(x)
+    _, dyp = _padded(dy)
+    ref = torch.nn.grad.conv2d_weight(nchw(x.to(torch.bfloat16).double()), (cout, cin, 3, 3), nchw(dy.to(torch.bfloat16).double()), padding=1)
+    dw = torch.full((cout, 3, 3, cin), float("nan"), device=DEV)
+    ops.conv3x3_wgrad_bf16(xp, dyp, dw, n, h, w, cin, cout)
+    close(f"conv3x3_wgrad_bf16[{n}x{h}x{w}x{cin}->{cout}]", dw, ref.permute(0, 2, 3, 1), rtol=5e-6)
+
+
+@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True)])
+def test_linear_bwd_bf16(m, k, j, use_mult):
+    dy = rnd(m, j, seed=68).to(torch.bfloat16)
+    w = rnd(j, k, seed=69, lo=-0.05, hi=0.05).to(torch.bfloat16)
+    x = rnd(m, k, seed=70).to(torch.bfloat16)
+    mult = (torch.rand(m, k, generator=torch.Generator().manual_seed(71)) >= 0.5).float() * 1.25 if use_mult else None
+    ref = dy.double() @ w.double()
+    if use_mult:
+        ref = ref * mult.double()
+    dx = torch.full((m, k), float("nan"), device=DEV)
+    ops.linear_bwd_dx_bf16(dy.to(DEV), w.to(DEV), dx, mult=None if mult is None else mult.to(DEV))
+    close(f"linear_bwd_dx_bf16[{m}x{j}->{k}]", dx, ref, rtol=3e-6)
+    dw = torch.full((j, k), float("nan"), device=DEV)
+    ops.linear_bwd_dw_bf16(dy.to(DEV), x.to(DEV), dw)
+    close(f"linear_bwd_dw_bf16[{m}: {j}x{k}]", dw, dy.double().t() @ x.double(), rtol=3e-6)
