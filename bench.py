@@ -115,6 +115,12 @@ def main():
                          "the north star's 1e-3 of the fp32 CPU reference; f32 = the reference's arithmetic on the fp32 matrix cores")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): anything libraries print meanwhile (RCCL prints a version banner to
+    # stdout at communicator creation) is diverted to stderr until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,7 +150,7 @@ def main():
     if args.no_audio:
         aud = None
     if distributed:
-        model.grad_sync = GradSync()
+        model.grad_sync = GradSync(compress="bf16" if args.dtype == "bf16" else None)
 
     for _ in range(args.warmup):
         model.train_step(aud, vis, lab)
@@ -177,7 +183,8 @@ def main():
             "config": {"workload": f"AVM train step (forward + broadcast-MSE + backward + fused Adam), {args.clips} clips x 16 frames = "
                                    f"{n} frames of 3x{h}x{w} + 30x30 MFCC per GPU; dropout live (device masks), BatchNorm train mode",
                        "frames_per_gpu": n, "h": h, "w": w, "global_clips_per_step": args.clips * world,
-                       "parallelism": f"dp{world}", "ddp_semantics": "local BN + local MSE per rank, gradient mean (standard DDP)",
+                       "parallelism": f"dp{world}", "ddp_semantics": "local BN + local MSE per rank, gradient mean (standard DDP)" +
+                       ("; linear5.weight gradient exchanged as bf16" if args.dtype == "bf16" and distributed else ""),
                        "params": int(sum(s.numel for s in model._specs)), "final_loss": float(loss.item())},
         }
         ev = events.get("conv_fwd", [])
@@ -193,7 +200,7 @@ def main():
                 except Exception:
                     traffic = None
             peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-            kname = ("gemm_bf16_kernel<ConvALoaderH, KCLoaderH> (conv2 + conv3 forward, bf16 MFMA implicit GEMM)" if args.dtype == "bf16"
+            kname = ("gemm_bf16_kernel<ConvAPadLoaderH, KCLoaderH> (conv2 + conv3 forward, bf16 MFMA implicit GEMM on zero-padded bf16 activations)" if args.dtype == "bf16"
                      else "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)")
             res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                "frac": achieved / peak, "traffic": traffic,
@@ -215,7 +222,10 @@ def main():
             except Exception as e:  # the bench line must still be printed
                 log(f"cpu_baseline failed: {e!r}")
                 res["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

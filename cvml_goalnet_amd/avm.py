@@ -470,8 +470,13 @@ class AVM(nn.Module):
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
                             G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
-        dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
-        ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, partials, n, hc, wc, c)
+        if self.precision == "bf16" and i > 1:
+            # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
+            dy = self._padbuf(f"dy{i}", n, hc, wc, c)
+            ops.bnpool_bwd_bf16p(dbn, p, idx, y, coef3, None, dy, partials, n, hc, wc, c)
+        else:
+            dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
+            ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, partials, n, hc, wc, c)
         ops.partials_sum(partials, STAT_PARTS, c, c, G(f"visbl.conv{i}.bias"))
         return dy
 
@@ -541,7 +546,7 @@ class AVM(nn.Module):
         del dbn3
         st2 = ctx["st2"]
         if bf:
-            dyp3 = ops.to_bf16_padded(dy3, None, None, self._padbuf("dy3", n, hp2, wp2, 512), n, hp2, wp2, 512)
+            dyp3 = dy3
             self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
                         ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
         else:
@@ -564,7 +569,7 @@ class AVM(nn.Module):
         del dbn2
         st1 = ctx["st1"]
         if bf:
-            dyp2 = ops.to_bf16_padded(dy2, None, None, self._padbuf("dy2", n, hp1, wp1, 256), n, hp1, wp1, 256)
+            dyp2 = dy2
             self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
                         ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
         else:

@@ -391,6 +391,16 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void cast_f32_kernel(const __hip_bfloat16* __restrict__ x, float* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+        reinterpret_cast<float4*>(y)[2 * i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                          __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        reinterpret_cast<float4*>(y)[2 * i + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                                              __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+    }
+}
+
 // y = bf16(x * scale[c] + shift[c]), c = element index mod C (NHWC), C % 8 == 0
 __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
@@ -448,6 +458,15 @@ int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream) {
     GN_REQUIRE(aligned16(x) && aligned16(y_bf16), GOALNET_E_ALIGN, "cast_bf16: pointers must be 16-byte aligned");
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (__hip_bfloat16*)y_bf16, n / 8);
     GN_LAUNCH_CHECK("cast_bf16");
+    return 0;
+}
+
+int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream) {
+    GN_REQUIRE(x_bf16 && y, GOALNET_E_NULL, "cast_f32: null pointer");
+    GN_REQUIRE(n > 0 && n % 8 == 0, GOALNET_E_SHAPE, "cast_f32: element count must be a positive multiple of 8");
+    GN_REQUIRE(aligned16(x_bf16) && aligned16(y), GOALNET_E_ALIGN, "cast_f32: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)x_bf16, y, n / 8);
+    GN_LAUNCH_CHECK("cast_f32");
     return 0;
 }
 

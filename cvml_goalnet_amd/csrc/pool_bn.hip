@@ -9,6 +9,7 @@
 // Statistics are accumulated in fp64 and reduced through a fixed number (GOALNET_STAT_PARTS) of per-block
 // partial rows that a second kernel sums in a fixed order: deterministic, and accurate to the level of
 // ATen's CPU implementation (which accumulates float statistics in double).
+#include <hip/hip_bf16.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -296,9 +297,16 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
     slice_reduce_store(acc, 2, tid, reinterpret_cast<double*>(smem), row, row + C);
 }
 
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+}
+
+// dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
 __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restrict__ dz, const float* __restrict__ p,
                                                            const uint8_t* __restrict__ idx, const float* __restrict__ y,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
+                                                           __hip_bfloat16* __restrict__ dy_pad,
                                                            double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // dp [3][Wp][CS] floats, then idx [3][Wp][CS] bytes
     const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
@@ -315,7 +323,8 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
         const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + (int64_t)n * Hp * Wp * C + c0;
         const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
-        float* dyn = dy + (int64_t)n * Hc * Wc * C + c0;
+        float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
+        __hip_bfloat16* dpn = dy_pad ? dy_pad + (int64_t)n * (Hc + 2) * (Wc + 2) * C + c0 : nullptr;
         __syncthreads();
         for (int h = 0; h < Hc; ++h) {
             if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
@@ -359,7 +368,10 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
                 a4.y = yy.y > 0.f ? a4.y : 0.f;
                 a4.z = yy.z > 0.f ? a4.z : 0.f;
                 a4.w = yy.w > 0.f ? a4.w : 0.f;
-                *reinterpret_cast<float4*>(dyn + o) = a4;
+                if (dyn) *reinterpret_cast<float4*>(dyn + o) = a4;
+                if (dpn)
+                    *reinterpret_cast<uint2*>(dpn + ((int64_t)(h + 1) * (Wc + 2) + w + 1) * C) =
+                        make_uint2(pack_bf16x2(a4.x, a4.y), pack_bf16x2(a4.z, a4.w));
                 acc[0][0] += (double)a4.x; acc[0][1] += (double)a4.y; acc[0][2] += (double)a4.z; acc[0][3] += (double)a4.w;
             }
             __syncthreads();
@@ -445,12 +457,27 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
         hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
-                           dy, dbias_partials, N, Hc, Wc, C);
+                           dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("bnpool_bwd");
+    return 0;
+}
+
+int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+                             float* dy, void* dy_pad_bf16, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && idx && y && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: bad dims (C %% 32)");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p: alignment");
+    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
+    const size_t need = lds < 8192 ? 8192 : lds;
+    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+                       dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;
 }
 

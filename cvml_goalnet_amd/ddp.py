@@ -35,7 +35,13 @@ def bucket_slices(specs, arena_numel: int) -> List[Tuple[int, int]]:
 class GradSync:
     """Plugged into AVM.grad_sync; called by AVM.train_step between backward and Adam."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, compress=None):
+        """compress="bf16": bucket 1 (linear5.weight, 90-99.8 % of the bytes) travels as bf16 (summed in bf16 by RCCL) —
+        an extension for precision="bf16" runs, off by default (fp32 exchange, exact mean)."""
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
+        self.compress = compress
+        self._packed = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # GOALNET_DDP_FORCE=1: issue the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
@@ -46,10 +52,19 @@ class GradSync:
         if self.world == 1 and not self.force:
             return
         lo, hi = bucket_slices(model._specs, model._arena_numel)[k]
-        self._work.append(dist.all_reduce(model._garena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        g = model._garena[lo:hi]
+        if self.compress == "bf16" and k == 1 and g.is_cuda and (hi - lo) % 8 == 0:
+            from . import ops
+            self._packed = (ops.cast_bf16(g, torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)), g)
+            g = self._packed[0]
+        self._work.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self, model) -> float:
         for w in self._work:
             w.wait()
         self._work = []
+        if self._packed is not None:
+            from . import ops
+            ops.cast_f32(*self._packed)
+            self._packed = None
         return 1.0 / self.world

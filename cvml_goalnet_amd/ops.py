@@ -132,6 +132,13 @@ def bnpool_bwd(dz, p, idx, y, coef3, dy, dbias_partials, N, Hc, Wc, C):
                                    dbias_partials.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd")
 
 
+def bnpool_bwd_bf16p(dz, p, idx, y, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
+    _chk(dz, p, idx, y, coef3, dy, dypad, dbias_partials)
+    assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
+    check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), _p(dy),
+                                         dypad.data_ptr(), dbias_partials.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p")
+
+
 def partials_sum(partials, nparts, stride, C, out):
     _chk(partials, out)
     assert partials.dtype == torch.float64 and out.numel() == C
@@ -165,6 +172,13 @@ def cast_bf16(x, y):
     _chk(x, y)
     assert x.dtype == F32 and y.dtype == BF16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib().goalnet_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _s()), "cast_bf16")
+    return y
+
+
+def cast_f32(x, y):
+    _chk(x, y)
+    assert x.dtype == BF16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().goalnet_cast_f32(x.data_ptr(), y.data_ptr(), x.numel(), _s()), "cast_f32")
     return y
 
 

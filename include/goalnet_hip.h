@@ -86,6 +86,10 @@ int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const fl
  * [GOALNET_STAT_PARTS][C]) = per-block column sums of dy. */
 int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
                        float* dy, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream);
+/* same, writing dy as bf16 into the zero-padded layout of goalnet_to_bf16_padded (dy_pad_bf16 = padded pixel 0);
+ * the fp32 dy is optional (NULL when only the bf16 GEMMs consume it). */
+int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+                             float* dy, void* dy_pad_bf16, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
 
@@ -105,6 +109,8 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
  * The reference is fp32 (utils.py:37-47): this mode is an extension with its own tolerance (logits <= 1e-3). ---- */
 /* y_bf16[i] = bf16(x[i]); n % 8 == 0 */
 int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+/* y[i] = float(x_bf16[i]) (exact); n % 8 == 0 */
+int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
 /* y_bf16 = bf16(x * scale[c] + shift[c]), c = i mod C: the BatchNorm output utils.py:177/182/187, materialised in bf16 */
 int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);
 /* y = [relu](conv3x3(x_bf16 NHWC, w_bf16 OHWI) + bias), fp32 out; Cin % 64 == 0. Data gradient with flipped weights. */
