@@ -35,7 +35,8 @@ PROTOTYPES = {
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
-    "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "goalnet_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_cast_bf16": (c_int, [P, P, c_int64, P]),
@@ -46,7 +47,8 @@ PROTOTYPES = {
     "goalnet_linear_fwd_bf16": (c_int, [P, c_int64, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
     "goalnet_bf16_padded_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "goalnet_to_bf16_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_fwd_bf16p_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_linear_bwd_dx_bf16": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
@@ -65,6 +67,11 @@ PROTOTYPES = {
     "goalnet_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, P]),
     "goalnet_mse_bcast": (c_int, [P, P, c_int, P, P, P]),
     "goalnet_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, P]),
+    "goalnet_counter_add": (c_int, [P, c_int64, P]),
+    "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, P]),
+    "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_float, P]),
+    "goalnet_rows_gather": (c_int, [P, P, c_int64, c_int, P, P]),
+    "goalnet_rows_scatter": (c_int, [P, P, c_int64, c_int, P, P]),
 }
 
 _lib = None

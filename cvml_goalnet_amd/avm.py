@@ -108,6 +108,7 @@ class AVM(nn.Module):
         self._arena = self._garena = self._adam_m = self._adam_v = None
         self._hw3 = self._l2 = None
         self._adam_t = 0
+        self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
         self._materialized = False
         self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
@@ -167,6 +168,11 @@ class AVM(nn.Module):
             raise GoalnetError("the MI355X AVM needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         ops.lib()
 
+    def _make_state(self):
+        """Device counters read by the graph-capturable kernels (csrc/stepstate.hip); host mirrors: _adam_t, _drop_step."""
+        self._require_device()
+        self._state = torch.tensor([self._adam_t, self._drop_step, 0, 0], dtype=torch.int64, device=self._device)
+
     def _materialize(self, hw3: int, l2: int, init: bool = True):
         """Fix the Lazy shapes (first forward or load_state_dict) and build the arena. Parameters are
         materialised IN PLACE so an optimizer created earlier keeps valid references (main.py:70)."""
@@ -176,6 +182,8 @@ class AVM(nn.Module):
                                    f"(got {512 * hw3}), audbl.linear3 {128 * (self._l2 or 0)} (got {128 * l2})")
             return
         self._require_device()
+        if self._state is None:
+            self._make_state()
         self._hw3, self._l2 = hw3, l2
         self._specs = self._param_specs(hw3, l2)
         dev = self._device
@@ -311,11 +319,11 @@ class AVM(nn.Module):
                 if tuple(m.shape) != (n, wdt):
                     raise RuntimeError(f"dropout mask shape {tuple(m.shape)} != {(n, wdt)}")
             return list(self._given_masks)
-        out = []
-        for li, wdt in enumerate((512, 512, 512, 256, 128)):
-            m = torch.empty(n, wdt, dtype=F32, device=self._device)
-            ops.dropout_mask(m, self.dropout_seed, TID_DROP + 8 * self._drop_step + li, DROP_P)
-            out.append(m)
+        # one launch for the five masks; the draw index is the device counter state[1] (graph-capturable)
+        widths = (512, 512, 512, 256, 128)
+        buf = torch.empty(n * sum(widths), dtype=F32, device=self._device)
+        out = ops.dropout_masks_dev(buf, n, widths, self.dropout_seed, TID_DROP, 8, self._state[1], DROP_P)
+        ops.counter_add(self._state[1], 1)
         self._drop_step += 1
         return out
 
@@ -417,18 +425,23 @@ class AVM(nn.Module):
         cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
         mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         k5 = 512 * hp3 * wp3
-        if bf:
+        # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
+        # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
+        bf5 = bf and n > 16
+        if bf5:
             xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
             w5b = ops.cast_bf16(P("visbl.linear5.weight"), torch.empty(512 * k5, dtype=BF16, device=dev))
             ops.linear_fwd_bf16(xh3.view(n, k5), w5b, P("visbl.linear5.bias"), cat[:, voff:], relu=True,
                                 dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
             if save:
-                ctx.update(xh1=xh1, xh2=xh2, xh3=xh3, w5b=w5b, padgen=(self._padgen["x1"], self._padgen["x2"]))
+                ctx.update(xh3=xh3, w5b=w5b)
             del xh3, w5b
         else:
             ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
                            scale=st3[2], shift=st3[3], bnC=512, dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
 
+        if bf and save:
+            ctx.update(xh1=xh1, xh2=xh2, bf5=bf5, padgen=(self._padgen["x1"], self._padgen["x2"]))
         a1 = a2 = None
         if self.audio_included:
             # ---- AudBl, utils.py:214-227
@@ -529,7 +542,7 @@ class AVM(nn.Module):
         if bf and ctx["padgen"] != (self._padgen["x1"], self._padgen["x2"]):
             raise RuntimeError("precision='bf16': a second training-mode forward overwrote the saved bf16 operands before "
                                "backward ran; call backward after each forward (as the reference's loop does)")
-        if bf:
+        if bf and ctx["bf5"]:
             dz5b = ops.cast_bf16(dz5.contiguous(), torch.empty(n, 512, dtype=torch.bfloat16, device=dev))
             ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight"))
             if on_bucket:
@@ -652,7 +665,8 @@ class AVM(nn.Module):
             self._adam_m = torch.zeros_like(self._arena)
             self._adam_v = torch.zeros_like(self._arena)
         self._adam_t += 1
-        ops.adam_step(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._adam_t, grad_scale)
+        ops.counter_add(self._state[0], 1)
+        ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0], grad_scale)
 
     def grad_of(self, name) -> torch.Tensor:
         """Gradient of a parameter as a strided view with the reference's logical shape (linear5: (512, C*HW) copy)."""

@@ -184,12 +184,28 @@ __global__ __launch_bounds__(256) void conv1_wgrad_v2_kernel(const float* __rest
     if (kg == 0) prow[CO * KP + co] = accb;
 }
 
+// 16 columns x 16 part lanes per block; lane-group totals added in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                 float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CO * KP + CO) return;
+    __shared__ double sm[256];
+    constexpr int ROW = CO * KP + CO;
+    const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (i < ROW) {
+        int p = pg;
+        for (; p + 16 < nparts; p += 32) {
+            a0 += (double)partial[(int64_t)p * ROW + i];
+            a1 += (double)partial[(int64_t)(p + 16) * ROW + i];
+        }
+        for (; p < nparts; p += 16) a0 += (double)partial[(int64_t)p * ROW + i];
+    }
+    sm[pg * 16 + cl] = a0 + a1;
+    __syncthreads();
+    if (pg != 0 || i >= ROW) return;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partial[(int64_t)p * (CO * KP + CO) + i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k * 16 + cl];
     if (i < CO * KP) dw[i] = (float)s;
     else if (db) db[i - CO * KP] = (float)s;
 }
@@ -232,7 +248,7 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
         hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(WG_PARTS), dim3(256), 0, (hipStream_t)stream, x_nchw, dy_nhwc,
                            (float*)ws, N, H, W, Ho, Wo);
     GN_LAUNCH_CHECK("conv1_wgrad");
-    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((CO * KP + CO + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3((CO * KP + CO + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, WG_PARTS, dw_ohwi, dbias);
     GN_LAUNCH_CHECK("conv1_wgrad.reduce");
     return 0;

@@ -552,18 +552,39 @@ int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shif
     return 0;
 }
 
+static int conv_splits_h(int64_t M, int Cin, int Cout) {
+    return conv_fwd_splits(((M + BM - 1) / BM) * ((Cout + BN - 1) / BN), 9 * Cin / BKH);
+}
+
+size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int64_t M = (int64_t)N * H * W;
+    const int s = conv_splits_h(M, Cin, Cout);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)Cout * sizeof(float) : 0;
+}
+
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, void* stream) {
+                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     GN_REQUIRE(x_pad && w_bf16 && y, GOALNET_E_NULL, "conv3x3_fwd_bf16p: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: non-positive dim");
     GN_REQUIRE(Cin % BKH == 0 && Cout % 4 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: Cin %% 64, Cout %% 4");
     GN_REQUIRE(aligned16(x_pad) && aligned16(w_bf16) && aligned16(y), GOALNET_E_ALIGN, "conv3x3_fwd_bf16p: alignment");
     const int64_t M = (int64_t)N * H * W;
     GN_REQUIRE((int64_t)N * (H + 2) * (W + 2) < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: too many pixels");
+    hipStream_t st = (hipStream_t)stream;
     ConvAPadLoaderH::P ap{(const __hip_bfloat16*)x_pad, H, W, Cin, M};
     KCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, (int64_t)9 * Cin, Cout};
-    EpiP ep{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
-    return launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, 1, 0, (hipStream_t)stream);
+    const EpiP efinal{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
+    EpiP ep = efinal;
+    const int nsplit = ws ? conv_splits_h(M, Cin, Cout) : 1;
+    if (nsplit > 1) {
+        GN_REQUIRE(aligned16(ws) && ws_bytes >= goalnet_conv3x3_fwd_bf16p_ws_bytes(N, H, W, Cin, Cout), GOALNET_E_WORKSPACE,
+                   "conv3x3_fwd_bf16p: workspace too small or misaligned");
+        ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
+    }
+    const int rc = launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, st);
+    if (rc || nsplit == 1) return rc;
+    return launch_splitk_reduce("conv3x3_fwd_bf16p.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }
 
 static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {

@@ -97,4 +97,16 @@ __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int m_fa
 int launch_splitk_reduce(const char* name, const float* slabs, int nsplit, int64_t slab_stride, const EpiP& ep, hipStream_t st);
 int pick_splits(int64_t tiles, int ktiles);
 
+// Convolutions over few pixels (the reference's 10-frame sub-batches at 40x40: 10..40 output tiles) cannot fill 256 CUs
+// with output tiles alone: split K into slabs (>= 4 K-tiles each, ~512 blocks), reduced in a fixed order.
+inline int conv_fwd_splits(int64_t tiles, int ktiles) {
+    if (tiles >= 256 || ktiles < 8) return 1;
+    int64_t s = (512 + tiles - 1) / tiles;
+    const int64_t smax = ktiles / 4;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    const int kps = (int)((ktiles + s - 1) / s);
+    return (ktiles + kps - 1) / kps;   // no empty splits
+}
+
 }  // namespace goalnet

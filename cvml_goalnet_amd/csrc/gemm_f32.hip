@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gemm_common.h"
+#include "skinny.h"
 
 using namespace goalnet;
 
@@ -496,8 +497,20 @@ int pick_splits(int64_t tiles, int ktiles) {
 // =================================================================================================
 extern "C" {
 
+static int conv_splits_f32(int64_t M, int Cin, int Cout) {
+    return conv_fwd_splits(((M + BM - 1) / BM) * ((Cout + BN - 1) / BN), 9 * Cin / BK);
+}
+
+size_t goalnet_conv3x3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int64_t M = (int64_t)N * H * W;
+    const int s = conv_splits_f32(M, Cin, Cout);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)Cout * sizeof(float) : 0;
+}
+
 int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, const float* w,
-                        const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout, void* stream) {
+                        const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, void* stream) {
     GN_REQUIRE(x && w && y, GOALNET_E_NULL, "conv3x3_fwd: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "conv3x3_fwd: scale/shift must both be set or both NULL");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd: non-positive dim");
@@ -509,14 +522,26 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
     GN_REQUIRE(M < (1ll << 31) - 256, GOALNET_E_SHAPE, "conv3x3_fwd: N*H*W too large");
     hipStream_t st = (hipStream_t)stream;
     KCLoader<false>::P bp{w, (int64_t)9 * Cin, Cout, nullptr, nullptr, 1};
-    EpiP ep{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
+    const EpiP efinal{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
+    EpiP ep = efinal;
     const int ktiles = 9 * Cin / BK;
+    // split K only when the caller supplied the workspace goalnet_conv3x3_fwd_ws_bytes asks for
+    int nsplit = ws ? conv_splits_f32(M, Cin, Cout) : 1;
+    if (nsplit > 1) {
+        GN_REQUIRE(aligned16(ws) && ws_bytes >= goalnet_conv3x3_fwd_ws_bytes(N, H, W, Cin, Cout), GOALNET_E_WORKSPACE,
+                   "conv3x3_fwd: workspace too small or misaligned");
+        ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
+    }
+    int rc;
     if (scale) {
         ConvALoader<true>::P ap{x, H, W, Cin, M, scale, shift};
-        return launch_gemm<ConvALoader<true>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, 1, 0, st);
+        rc = launch_gemm<ConvALoader<true>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
+    } else {
+        ConvALoader<false>::P ap{x, H, W, Cin, M, nullptr, nullptr};
+        rc = launch_gemm<ConvALoader<false>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
     }
-    ConvALoader<false>::P ap{x, H, W, Cin, M, nullptr, nullptr};
-    return launch_gemm<ConvALoader<false>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, 1, 0, st);
+    if (rc || nsplit == 1) return rc;
+    return launch_splitk_reduce("conv3x3_fwd.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }
 
 static int wgrad_splits(int64_t M, int Cin, int Cout) {
@@ -583,6 +608,7 @@ static int linear_splits(int M, int64_t K, int J) {
 
 size_t goalnet_linear_fwd_ws_bytes(int M, int64_t K, int J) {
     if (M <= 0 || K <= 0 || J <= 0) return 0;
+    if (M <= SKINNY_MAX_M) return skinny_fwd_ws_bytes(M, K, J);
     const int s = linear_splits(M, K, J);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)J * sizeof(float) : 0;
 }
@@ -600,10 +626,15 @@ int goalnet_linear_fwd(const float* x, int64_t ldx, const float* scale, const fl
     GN_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(scale) && aligned16(shift) && ldx % 4 == 0 && ldy % 4 == 0,
                GOALNET_E_ALIGN, "linear_fwd: pointers / leading dims must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    EpiP efinal{(dropmask || mult_out) ? EPI_FULL : EPI_BIAS_RELU, y, ldy, M, J, bias, relu, dropmask, ldmask, mult_out, ldmult, 0};
+    if (M <= SKINNY_MAX_M) {          // the reference's 10-frame sub-batches: weight-streaming kernels (skinny.hip)
+        const size_t need = skinny_fwd_ws_bytes(M, K, J);
+        GN_REQUIRE(need == 0 || (ws && aligned16(ws) && ws_bytes >= need), GOALNET_E_WORKSPACE, "linear_fwd: workspace too small");
+        return skinny_linear_fwd(x, ldx, scale, shift, bnC, w, efinal, M, K, J, ws, st);
+    }
     const int nsplit = linear_splits(M, K, J);
     const int ktiles = (int)(K / BK);
     KCLoader<false>::P bp{w, K, J, nullptr, nullptr, 1};
-    EpiP efinal{(dropmask || mult_out) ? EPI_FULL : EPI_BIAS_RELU, y, ldy, M, J, bias, relu, dropmask, ldmask, mult_out, ldmult, 0};
     EpiP ep = efinal;
     if (nsplit > 1) {
         GN_REQUIRE(ws && aligned16(ws), GOALNET_E_WORKSPACE, "linear_fwd: split-K needs a 16-byte aligned workspace");
@@ -631,6 +662,8 @@ int goalnet_linear_bwd_dx(const float* dy, int64_t lddy, const float* w, const f
     GN_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && lddy % 4 == 0 && lddx % 4 == 0,
                GOALNET_E_ALIGN, "linear_bwd_dx: pointers / leading dims must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (M <= SKINNY_MAX_M && (!mult || (aligned16(mult) && ldmult % 4 == 0)))
+        return skinny_linear_dx(dy, lddy, w, mult, ldmult, dx, lddx, M, K, J, st);
     KCLoader<false>::P ap{dy, lddy, M, nullptr, nullptr, 1};
     MCLoader<false>::P bp{w, K, (int)K, J, nullptr, nullptr, 1};
     EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};
@@ -648,6 +681,7 @@ int goalnet_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t
     GN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw) && aligned16(scale) && aligned16(shift) && lddy % 4 == 0 && ldx % 4 == 0,
                GOALNET_E_ALIGN, "linear_bwd_dw: pointers / leading dims must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (M <= SKINNY_MAX_M) return skinny_linear_dw(dy, lddy, x, ldx, scale, shift, bnC, dw, M, K, J, st);
     const int ktiles = (M + BK - 1) / BK;
     MCLoader<false>::P ap{dy, lddy, J, M, nullptr, nullptr, 1};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};

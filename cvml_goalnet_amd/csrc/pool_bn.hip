@@ -48,6 +48,34 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV][4], int G, in
 }
 
 // ---- forward: p = maxpool3x3s1(y), idx = argmax (first maximum in kh,kw scan order, NaN wins, as ATen's
+// ---- column sums over the PARTS partial rows. One block = 16 columns x 16 part lanes: lane group pg sums rows pg, pg+16, ...
+// (4 independent accumulators), the 16 lane-group totals are then added in a fixed order -> deterministic, and ~64
+// dependent loads per thread instead of 1024 (these kernels were 240 us at N = 10 when one thread walked all rows).
+__device__ __forceinline__ double column_sum16(const double* __restrict__ col0, int nparts, int64_t stride, bool valid,
+                                               double* sm /* [16][16] */) {
+    const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (valid) {
+        int pt = pg;
+        for (; pt + 48 < nparts; pt += 64) {
+            a0 += col0[(int64_t)pt * stride];
+            a1 += col0[(int64_t)(pt + 16) * stride];
+            a2 += col0[(int64_t)(pt + 32) * stride];
+            a3 += col0[(int64_t)(pt + 48) * stride];
+        }
+        for (; pt < nparts; pt += 16) a0 += col0[(int64_t)pt * stride];
+    }
+    __syncthreads();                       // sm may still be read from a previous call
+    sm[pg * 16 + cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    double t = 0.0;
+    if (pg == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k * 16 + cl];
+    }
+    return t;
+}
+
 // max_pool2d CPU kernel), partial sums of p and p*p per channel.
 __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __restrict__ y, float* __restrict__ p,
                                                               uint8_t* __restrict__ idx, double* __restrict__ partials,
@@ -95,13 +123,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                          float* __restrict__ rvar, float momentum, float eps, double count,
                                                          int C, float* __restrict__ mean, float* __restrict__ invstd,
                                                          float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int pt = 0; pt < PARTS; ++pt) {
-        s += partials[(int64_t)pt * 2 * C + c];
-        q += partials[(int64_t)pt * 2 * C + C + c];
-    }
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = column_sum16(partials + c, PARTS, 2 * C, c < C, sm);
+    const double q = column_sum16(partials + C + c, PARTS, 2 * C, c < C, sm);
+    if (c >= C || threadIdx.x >= 16) return;
     const double m = s / count;
     double var = q / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -146,13 +172,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              double count, int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ coef3) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int pt = 0; pt < PARTS; ++pt) {
-        s += partials[(int64_t)pt * 2 * C + c];
-        q += partials[(int64_t)pt * 2 * C + C + c];
-    }
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = column_sum16(partials + c, PARTS, 2 * C, c < C, sm);
+    const double q = column_sum16(partials + C + c, PARTS, 2 * C, c < C, sm);
+    if (c >= C || threadIdx.x >= 16) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
@@ -383,11 +407,10 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restrict__ partials, int nparts, int64_t stride,
                                                           int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int pt = 0; pt < nparts; ++pt) s += partials[(int64_t)pt * stride + c];
-    out[c] = (float)s;
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = column_sum16(partials + c, nparts, stride, c < C, sm);
+    if (c < C && threadIdx.x < 16) out[c] = (float)s;
 }
 
 bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >> 2)) == 0; }
@@ -421,7 +444,7 @@ int goalnet_bn_finalize(const double* partials, const float* gamma, const float*
     GN_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift, GOALNET_E_NULL, "bn_finalize: null pointer");
     GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "bn_finalize: running stats must both be set or both NULL");
     GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_finalize: bad dims");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, gamma, beta,
                        running_mean, running_var, momentum, eps, (double)count, C, mean, invstd, scale, shift);
     GN_LAUNCH_CHECK("bn_finalize");
     return 0;
@@ -441,7 +464,7 @@ int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const fl
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream) {
     GN_REQUIRE(partials && gamma && mean && invstd && dgamma && dbeta && coef3, GOALNET_E_NULL, "bn_bwd_finalize: null pointer");
     GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_bwd_finalize: bad dims");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, gamma, mean,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, gamma, mean,
                        invstd, (double)count, C, dgamma, dbeta, coef3);
     GN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
@@ -484,7 +507,7 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream) {
     GN_REQUIRE(partials && out, GOALNET_E_NULL, "partials_sum: null pointer");
     GN_REQUIRE(nparts > 0 && C > 0 && stride >= C, GOALNET_E_SHAPE, "partials_sum: bad dims");
-    hipLaunchKernelGGL(partials_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
+    hipLaunchKernelGGL(partials_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
     GN_LAUNCH_CHECK("partials_sum");
     return 0;
 }

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void mse_bcast_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam defaults, single-tensor operation order), one pass over the flat arena.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float omb1, float omb2,
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b2, float omb1, float omb2,
                                       float eps, float step_size, float bc2_sqrt, float gs) {
     g *= gs;
     m = m + omb1 * (g - m);                    // exp_avg.lerp_(grad, 1 - beta1)
@@ -240,26 +240,32 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
     p = p - step_size * (m / denom);           // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
+// One kernel for both entry points (host step count / device step counter) so that they produce the same bits.
+// The scalars torch's _single_tensor_adam computes as python floats (doubles) are computed in fp64 here.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                  float* __restrict__ v, int64_t n, float b1, float b2, float omb1,
-                                                  float omb2, float eps, float step_size, float bc2_sqrt, float gs) {
+                                                  float* __restrict__ v, int64_t n, double lr, double beta1, double beta2,
+                                                  float eps, const int64_t* __restrict__ step_dev, int64_t step_host, float gs) {
+    const double t = (double)(step_dev ? *step_dev : step_host);
+    const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+    const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
-        adam1(pp.x, gg.x, mm.x, vv.x, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
-        adam1(pp.y, gg.y, mm.y, vv.y, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
-        adam1(pp.z, gg.z, mm.z, vv.z, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
-        adam1(pp.w, gg.w, mm.w, vv.w, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.x, gg.x, mm.x, vv.x, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.y, gg.y, mm.y, vv.y, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.z, gg.z, mm.z, vv.z, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(pp.w, gg.w, mm.w, vv.w, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        adam1(p[i], g[i], m[i], v[i], b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+        adam1(p[i], g[i], m[i], v[i], b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
     }
 }
 
@@ -358,20 +364,27 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
     return 0;
 }
 
+static int adam_launch(const char* who, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                       double beta2, double eps, const int64_t* step_dev, int64_t step_host, float grad_scale, void* stream) {
+    GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "%s: null pointer", who);
+    GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "%s: bad count", who);
+    GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "%s: arenas must be 16-byte aligned", who);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       (float)eps, step_dev, step_host, grad_scale);
+    GN_LAUNCH_CHECK(who);
+    return 0;
+}
+
 int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                       double beta2, double eps, int step, float grad_scale, void* stream) {
-    GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "adam_step: null pointer");
-    GN_REQUIRE(n > 0 && step >= 1, GOALNET_E_SHAPE, "adam_step: bad count or step");
-    GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "adam_step: arenas must be 16-byte aligned");
-    // host-side scalars exactly as torch's _single_tensor_adam computes them (python floats = doubles)
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)beta1,
-                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, grad_scale);
-    GN_LAUNCH_CHECK("adam_step");
-    return 0;
+    GN_REQUIRE(step >= 1, GOALNET_E_SHAPE, "adam_step: step is 1-based");
+    return adam_launch("adam_step", p, g, m, v, n, lr, beta1, beta2, eps, nullptr, step, grad_scale, stream);
+}
+
+int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                          double eps, const int64_t* step, float grad_scale, void* stream) {
+    GN_REQUIRE(step, GOALNET_E_NULL, "adam_step_dev: null step counter");
+    return adam_launch("adam_step_dev", p, g, m, v, n, lr, beta1, beta2, eps, step, 0, grad_scale, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,97 @@
+// Device-resident step state for the graph-captured sub-batch loop (the caller's loop is
+// /root/reference/main.py:169-198). A captured HIP graph bakes every host scalar into its kernel arguments, so the
+// three quantities that change from one sub-batch to the next live in device memory instead:
+//   * the Adam step count t (bias corrections, main.py:193 -> torch.optim.Adam),
+//   * the dropout stream index (which Bernoulli draw this forward uses, utils.py:170, 245-254),
+//   * the frame cursor / sub-batch index of the per-video loop (main.py:177-183).
+// The kernels here read them from int64 device counters; goalnet_counter_add advances them inside the graph.
+#include "common.h"
+#include "rng.h"
+
+using namespace goalnet;
+
+namespace {
+
+__global__ void counter_add_kernel(int64_t* ctr, int64_t delta) { *ctr += delta; }
+
+struct Widths { int w[8]; int64_t off[9]; };
+
+__global__ __launch_bounds__(256) void dropout_masks_dev_kernel(float* dst, int n, Widths ws, int layers, uint64_t seed,
+                                                                 uint32_t tid_base, uint32_t tid_stride,
+                                                                 const int64_t* __restrict__ step, float p, float scale) {
+    const uint32_t s = (uint32_t)*step;
+    const int64_t total = ws.off[layers];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (l + 1 < layers && i >= ws.off[l + 1]) ++l;
+        const uint64_t key = stream_key(seed, tid_base + tid_stride * s + (uint32_t)l);
+        dst[i] = unit24(key, i - ws.off[l]) >= p ? scale : 0.f;
+    }
+}
+
+// rows [cursor, cursor + nrows) of a row-major table <-> a compact block of nrows rows; 4-byte words
+template <bool GATHER>
+__global__ __launch_bounds__(256) void rows_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                       int64_t row_words, int64_t words, const int64_t* __restrict__ cursor) {
+    const int64_t base = *cursor * row_words;
+    const uint32_t* s = GATHER ? src + base : src;
+    uint32_t* d = GATHER ? dst : dst + base;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+unsigned grid1(int64_t n, int cap) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_counter_add(int64_t* counter, int64_t delta, void* stream) {
+    GN_REQUIRE(counter, GOALNET_E_NULL, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    GN_LAUNCH_CHECK("counter_add");
+    return 0;
+}
+
+int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, uint64_t seed, uint32_t tid_base,
+                              uint32_t tid_stride, const int64_t* step, float p, void* stream) {
+    GN_REQUIRE(dst && widths && step, GOALNET_E_NULL, "dropout_masks_dev: null pointer");
+    GN_REQUIRE(n > 0 && layers >= 1 && layers <= 8 && p >= 0.f && p < 1.f, GOALNET_E_SHAPE, "dropout_masks_dev: bad dims or p");
+    Widths ws;
+    ws.off[0] = 0;
+    for (int l = 0; l < layers; ++l) {
+        GN_REQUIRE(widths[l] > 0, GOALNET_E_SHAPE, "dropout_masks_dev: bad width");
+        ws.w[l] = widths[l];
+        ws.off[l + 1] = ws.off[l] + (int64_t)n * widths[l];
+    }
+    hipLaunchKernelGGL(dropout_masks_dev_kernel, dim3(grid1(ws.off[layers], 8192)), dim3(256), 0, (hipStream_t)stream, dst, n, ws,
+                       layers, seed, tid_base, tid_stride, step, p, 1.0f / (1.0f - p));
+    GN_LAUNCH_CHECK("dropout_masks_dev");
+    return 0;
+}
+
+int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream) {
+    GN_REQUIRE(table && block && cursor, GOALNET_E_NULL, "rows_gather: null pointer");
+    GN_REQUIRE(row_bytes > 0 && (row_bytes & 3) == 0 && nrows > 0, GOALNET_E_SHAPE, "rows_gather: rows must be a positive multiple of 4 bytes");
+    const int64_t words = row_bytes / 4 * nrows;
+    hipLaunchKernelGGL(rows_copy_kernel<true>, dim3(grid1(words, 2048)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)table,
+                       (uint32_t*)block, row_bytes / 4, words, cursor);
+    GN_LAUNCH_CHECK("rows_gather");
+    return 0;
+}
+
+int goalnet_rows_scatter(const void* block, void* table, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream) {
+    GN_REQUIRE(table && block && cursor, GOALNET_E_NULL, "rows_scatter: null pointer");
+    GN_REQUIRE(row_bytes > 0 && (row_bytes & 3) == 0 && nrows > 0, GOALNET_E_SHAPE, "rows_scatter: rows must be a positive multiple of 4 bytes");
+    const int64_t words = row_bytes / 4 * nrows;
+    hipLaunchKernelGGL(rows_copy_kernel<false>, dim3(grid1(words, 2048)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)block,
+                       (uint32_t*)table, row_bytes / 4, words, cursor);
+    GN_LAUNCH_CHECK("rows_scatter");
+    return 0;
+}
+
+}  // extern "C"

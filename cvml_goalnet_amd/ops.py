@@ -6,6 +6,8 @@ Tensors are fp32, on the GPU, in the device layouts named in the header (NHWC / 
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -150,8 +152,10 @@ def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
     assert scale is None or (scale.numel() == Cin and shift.numel() == Cin)
     assert bias is None or bias.numel() == Cout
+    nbytes = lib().goalnet_conv3x3_fwd_ws_bytes(N, H, W, Cin, Cout)       # > 0 only for small N (split-K slabs)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=x.device) if nbytes else None
     check(lib().goalnet_conv3x3_fwd(x.data_ptr(), _p(scale), _p(shift), w.data_ptr(), _p(bias), int(relu), y.data_ptr(),
-                                    N, H, W, Cin, Cout, _s()), "conv3x3_fwd")
+                                    N, H, W, Cin, Cout, _p(ws), nbytes, _s()), "conv3x3_fwd")
     return y
 
 
@@ -218,8 +222,10 @@ def conv3x3_fwd_bf16p(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(xpad, w, bias, y)
     assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == F32
     assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
-    check(lib().goalnet_conv3x3_fwd_bf16p(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
-          "conv3x3_fwd_bf16p")
+    nbytes = lib().goalnet_conv3x3_fwd_bf16p_ws_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=y.device) if nbytes else None
+    check(lib().goalnet_conv3x3_fwd_bf16p(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout,
+                                          _p(ws), nbytes, _s()), "conv3x3_fwd_bf16p")
     return y
 
 
@@ -372,3 +378,57 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     assert g.numel() == n and m.numel() == n and v.numel() == n
     check(lib().goalnet_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, step, grad_scale,
                                   _s()), "adam_step")
+
+
+# ---- device-resident step state (graph-capturable variants; include/goalnet_hip.h "device-resident step state") ----
+I64 = torch.int64
+
+
+def _ctr(t):
+    assert t.is_cuda and t.dtype == I64 and t.numel() == 1
+    return t.data_ptr()
+
+
+def counter_add(counter, delta):
+    check(lib().goalnet_counter_add(_ctr(counter), int(delta), _s()), "counter_add")
+
+
+def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p):
+    """dst: flat fp32 buffer of n*sum(widths); returns the per-layer (n, width) views."""
+    _chk(dst)
+    total = n * sum(widths)
+    assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() == total
+    arr = (ctypes.c_int * len(widths))(*widths)
+    check(lib().goalnet_dropout_masks_dev(dst.data_ptr(), n, arr, len(widths), seed, tid_base, tid_stride, _ctr(step), p, _s()),
+          "dropout_masks_dev")
+    out, off = [], 0
+    for wdt in widths:
+        out.append(dst[off:off + n * wdt].view(n, wdt))
+        off += n * wdt
+    return out
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _chk(p, g, m, v)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    check(lib().goalnet_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
+                                      grad_scale, _s()), "adam_step_dev")
+
+
+def rows_gather(table, block, nrows, cursor):
+    """block[0:nrows] = table[cursor : cursor + nrows]; rows are the leading dimension of contiguous tensors."""
+    _chk(table, block)
+    assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+    row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
+    assert block.numel() * block.element_size() == row_bytes * nrows
+    check(lib().goalnet_rows_gather(table.data_ptr(), block.data_ptr(), row_bytes, nrows, _ctr(cursor), _s()), "rows_gather")
+
+
+def rows_scatter(block, table, nrows, cursor):
+    """table[cursor : cursor + nrows] = block[0:nrows]"""
+    _chk(table, block)
+    assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+    row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
+    assert block.numel() * block.element_size() == row_bytes * nrows
+    check(lib().goalnet_rows_scatter(block.data_ptr(), table.data_ptr(), row_bytes, nrows, _ctr(cursor), _s()), "rows_scatter")

@@ -97,8 +97,13 @@ int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int
 /* y = [relu](conv(bnapply(x), w) + bias).  scale/shift (per input channel) may be NULL (no BN on load);
  * zero padding is applied AFTER the affine, as the reference pads the BatchNorm output. bias may be
  * NULL. Also computes the data gradient when called with goalnet_conv3x3_weight_flip'ed weights. */
+/* Few pixels (the reference's 10-frame sub-batches, main.py:177-184) give too few output tiles for 256 CUs: with a
+ * workspace of goalnet_conv3x3_fwd_ws_bytes (0 = not needed) K is split into slabs that are summed in a fixed order.
+ * ws may be NULL (no split; same result up to fp32 summation order). */
+size_t goalnet_conv3x3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, const float* w_ohwi,
-                        const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+                        const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, void* stream);
 /* dw[Cout][3][3][Cin] = sum_m dy[m][co] * bnapply(x)[m + tap][ci]; split over m, deterministic. */
 size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
@@ -128,8 +133,9 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
  * the caller zeroes the whole buffer once (only interior pixels are ever written). */
 int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems, int64_t* offset_elems);
 int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);
+size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout);   /* split-K slabs, as goalnet_conv3x3_fwd */
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, void* stream);
+                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
                                int N, int H, int W, int Cin, int Cout, void* stream);
@@ -188,6 +194,23 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 /* g is scaled by grad_scale first (1/world_size after a SUM all-reduce). `step` is 1-based. */
 int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                       double beta2, double eps, int step, float grad_scale, void* stream);
+
+/* ---- device-resident step state: what a captured HIP graph cannot take as host scalars -------------
+ * The reference's per-video loop (/root/reference/main.py:169-198) runs one optimizer step per <=10 frames; captured
+ * as one graph per sub-batch, the Adam step count, the dropout draw index and the frame cursor must be read from
+ * device memory. All counters are int64 in device memory. */
+int goalnet_counter_add(int64_t* counter, int64_t delta, void* stream);
+/* `layers` masks back to back in dst: mask l is (n, widths[l]) row-major, drawn from stream
+ * tid_base + tid_stride * (*step) + l — the same bits as goalnet_dropout_mask with that tensor_id. widths: host array. */
+int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, uint64_t seed, uint32_t tid_base,
+                              uint32_t tid_stride, const int64_t* step, float p, void* stream);
+/* goalnet_adam_step with the 1-based step count read from *step */
+int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                          double beta2, double eps, const int64_t* step, float grad_scale, void* stream);
+/* block[0:nrows] = table[*cursor : *cursor + nrows]  (batch_frames[a:b], main.py:181-184); row_bytes % 4 == 0 */
+int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
+/* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */
+int goalnet_rows_scatter(const void* block, void* table, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 
 #ifdef __cplusplus
 }

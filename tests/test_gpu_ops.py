@@ -205,6 +205,9 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c):
     (37, 640, 512, False, True, 0),        # fusion.0
     (130, 512, 256, False, False, 0),      # ragged M over two tiles
     (1, 1024, 128, False, False, 512),     # audbl.linear3, N = 1
+    (16, 1056, 260, False, True, 0),       # weight-streaming path: largest row count, ragged J block, two K slabs
+    (7, 41472, 512, True, False, 128),     # a ragged last sub-batch of the reference's loop
+    (17, 41472, 512, True, True, 0),       # first row count on the MFMA path
 ])
 def test_linear_fwd(m, k, j, affine, mask, ldextra):
     x = rnd(m, k, seed=22)
@@ -234,7 +237,8 @@ def test_linear_fwd(m, k, j, affine, mask, ldextra):
         assert torch.isnan(ybuf[:, :ldextra]).all(), "wrote outside the column slice"
 
 
-@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True), (1, 256, 128, True)])
+@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True), (1, 256, 128, True),
+                                            (16, 1000, 96, True), (5, 41472, 512, True), (12, 640, 1056, True)])
 def test_linear_bwd_dx(m, k, j, use_mult):
     dy = rnd(m, j, seed=28)
     w = rnd(j, k, seed=29, lo=-0.05, hi=0.05)
@@ -247,7 +251,8 @@ def test_linear_bwd_dx(m, k, j, use_mult):
     close(f"linear_bwd_dx[{m}x{j}->{k}]", dx, ref, rtol=3e-6)
 
 
-@pytest.mark.parametrize("m,k,j,affine", [(10, 41472, 512, True), (37, 640, 512, False), (130, 512, 256, False), (1, 1024, 128, False)])
+@pytest.mark.parametrize("m,k,j,affine", [(10, 41472, 512, True), (37, 640, 512, False), (130, 512, 256, False), (1, 1024, 128, False),
+                                          (16, 1028, 36, False), (12, 41472, 512, True), (3, 2048, 512, True)])
 def test_linear_bwd_dw(m, k, j, affine):
     dy = rnd(m, j, seed=31)
     x = rnd(m, k, seed=32)
