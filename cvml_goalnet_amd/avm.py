@@ -362,7 +362,7 @@ class AVM(nn.Module):
         dev = self._device
         p = torch.empty(n, hc - 2, wc - 2, c, dtype=F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
-        partials = torch.empty(STAT_PARTS * 2 * c, dtype=torch.float64, device=dev)
+        partials = torch.empty(ops.stat_parts(n) * 2 * c, dtype=torch.float64, device=dev)     # one row per frame
         ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
         bn = getattr(self.visbl, f"bnorm{i}")
         st = torch.empty(4, c, dtype=F32, device=dev)
@@ -478,19 +478,20 @@ class AVM(nn.Module):
         G = self._gflat
         p, idx, y, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"y{i}"], ctx[f"st{i}"]
         npix = n * (hc - 2) * (wc - 2)
-        partials = torch.empty(STAT_PARTS * 2 * c, dtype=torch.float64, device=dev)
+        partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
         ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, npix, c)
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
                             G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
+        dparts = torch.empty(ops.stat_parts(n) * c, dtype=torch.float64, device=dev)            # dbias partials, one row per frame
         if self.precision == "bf16" and i > 1:
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
             dy = self._padbuf(f"dy{i}", n, hc, wc, c)
-            ops.bnpool_bwd_bf16p(dbn, p, idx, y, coef3, None, dy, partials, n, hc, wc, c)
+            ops.bnpool_bwd_bf16p(dbn, p, idx, y, coef3, None, dy, dparts, n, hc, wc, c)
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
-            ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, partials, n, hc, wc, c)
-        ops.partials_sum(partials, STAT_PARTS, c, c, G(f"visbl.conv{i}.bias"))
+            ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, dparts, n, hc, wc, c)
+        ops.partials_sum(dparts, ops.stat_parts(n), c, c, G(f"visbl.conv{i}.bias"))
         return dy
 
     def backward_device(self, ctx, dout, on_bucket=None):

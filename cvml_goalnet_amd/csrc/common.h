@@ -44,6 +44,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// DPP (data-parallel primitive) moves: a cross-lane operand fetch inside the VALU, ~10x cheaper than the ds_bpermute
+// behind __shfl_xor. old = 0 for lanes outside ROW_MASK.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each aligned group of 16 lanes (a DPP row), returned to all 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// sum over the 64 lanes, returned as a wave-uniform value (fixed order => deterministic)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);          // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4E>(v);          // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x141>(v);         // row_half_mirror: the other quad pair of each 8 lanes
+    v += dpp_mov<0x140>(v);         // row_mirror: the other half of each row of 16
+    v += dpp_mov<0x142, 0xA>(v);    // row_bcast:15 -> rows 1 and 3 add the totals of rows 0 and 2
+    v += dpp_mov<0x143, 0xC>(v);    // row_bcast:31 -> rows 2 and 3 add the total of rows 0..1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

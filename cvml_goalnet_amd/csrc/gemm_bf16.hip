@@ -591,7 +591,7 @@ static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {
     const int64_t tiles = (int64_t)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
     const int ktiles = (int)((Mp + BKH - 1) / BKH);
     int64_t s = (2048 + tiles - 1) / tiles;
-    const int64_t smax = ktiles / 16 > 1 ? ktiles / 16 : 1;
+    const int64_t smax = ktiles / 4 > 1 ? ktiles / 4 : 1;      // >= 4 K-tiles per split (small sub-batches: few pixels)
     if (s > smax) s = smax;
     if (s > 512) s = 512;
     const int kps = (int)((ktiles + s - 1) / s);

@@ -548,7 +548,7 @@ static int wgrad_splits(int64_t M, int Cin, int Cout) {
     const int64_t tiles = (int64_t)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
     const int ktiles = (int)((M + BK - 1) / BK);
     int64_t s = (2048 + tiles - 1) / tiles;
-    const int64_t smax = ktiles / 16 > 1 ? ktiles / 16 : 1;
+    const int64_t smax = ktiles / 4 > 1 ? ktiles / 4 : 1;      // >= 4 K-tiles per split (small sub-batches: few pixels)
     if (s > smax) s = smax;
     if (s > 512) s = 512;
     const int kps = (int)((ktiles + s - 1) / s);

@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, float momentum, float eps, double count,
-                                                         int C, float* __restrict__ mean, float* __restrict__ invstd,
+                                                         int nparts, int C, float* __restrict__ mean, float* __restrict__ invstd,
                                                          float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ double sm[256];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = column_sum16(partials + c, PARTS, 2 * C, c < C, sm);
-    const double q = column_sum16(partials + C + c, PARTS, 2 * C, c < C, sm);
+    const double s = column_sum16(partials + c, nparts, 2 * C, c < C, sm);
+    const double q = column_sum16(partials + C + c, nparts, 2 * C, c < C, sm);
     if (c >= C || threadIdx.x >= 16) return;
     const double m = s / count;
     double var = q / count - m * m;
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             double count, int C, float* __restrict__ dgamma,
+                                                             double count, int nparts, int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ coef3) {
     __shared__ double sm[256];
     const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-    const double s = column_sum16(partials + c, PARTS, 2 * C, c < C, sm);
-    const double q = column_sum16(partials + C + c, PARTS, 2 * C, c < C, sm);
+    const double s = column_sum16(partials + c, nparts, 2 * C, c < C, sm);
+    const double q = column_sum16(partials + C + c, nparts, 2 * C, c < C, sm);
     if (c >= C || threadIdx.x >= 16) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
     const int slot = blockIdx.x / ccn, c0 = (blockIdx.x % ccn) * CS + l8 * 4;
     const int Hp = Hc - 2, Wp = Wc - 2;
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int n = slot; n < N; n += PARTS) {
+    for (int n = slot; n < N; n += (int)gridDim.x / ccn) {
         const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
         float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         uint8_t* in = idx ? idx + (int64_t)n * Hp * Wp * C + c0 : nullptr;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
     const float4 cbv = *reinterpret_cast<const float4*>(coef3 + C + c0);
     const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + c0);
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int n = slot; n < N; n += PARTS) {
+    for (int n = slot; n < N; n += (int)gridDim.x / ccn) {
         const float* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
         const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + (int64_t)n * Hp * Wp * C + c0;
@@ -419,9 +419,14 @@ bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >>
 
 extern "C" {
 
-int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials,
+int goalnet_stat_parts(int64_t units) { return units < 1 ? 1 : units > PARTS ? PARTS : (int)units; }
+
+#define GN_PARTS_OK(name) GN_REQUIRE(nparts >= 1 && nparts <= PARTS, GOALNET_E_SHAPE, name ": nparts=%d must be in [1, %d]", nparts, PARTS)
+
+int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials, int nparts,
                              int N, int Hc, int Wc, int C, void* stream) {
     GN_REQUIRE(y && p && partials, GOALNET_E_NULL, "pool_bnstats_fwd: null pointer");
+    GN_PARTS_OK("pool_bnstats_fwd");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3, GOALNET_E_SHAPE, "pool_bnstats_fwd: need Hc, Wc >= 3");
     GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bnstats_fwd: C=%d must be 4*2^k, <= 1024", C);
     GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
@@ -429,60 +434,64 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
-        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
+        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
                            partials, N, Hc, Wc, C);
     } else {
-        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
+        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("pool_bnstats_fwd");
     return 0;
 }
 
-int goalnet_bn_finalize(const double* partials, const float* gamma, const float* beta,
+int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int64_t count,
                         int C, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     GN_REQUIRE(partials && gamma && beta && mean && invstd && scale && shift, GOALNET_E_NULL, "bn_finalize: null pointer");
     GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "bn_finalize: running stats must both be set or both NULL");
     GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_finalize: bad dims");
+    GN_PARTS_OK("bn_finalize");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, gamma, beta,
-                       running_mean, running_var, momentum, eps, (double)count, C, mean, invstd, scale, shift);
+                       running_mean, running_var, momentum, eps, (double)count, nparts, C, mean, invstd, scale, shift);
     GN_LAUNCH_CHECK("bn_finalize");
     return 0;
 }
 
 int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
-                          double* partials, int64_t npix, int C, void* stream) {
+                          double* partials, int nparts, int64_t npix, int C, void* stream) {
     GN_REQUIRE(dz && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce: null pointer");
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
+    GN_PARTS_OK("bn_bwd_reduce");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
     GN_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
 
-int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const float* mean, const float* invstd,
+int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream) {
     GN_REQUIRE(partials && gamma && mean && invstd && dgamma && dbeta && coef3, GOALNET_E_NULL, "bn_bwd_finalize: null pointer");
     GN_REQUIRE(C > 0 && count > 0, GOALNET_E_SHAPE, "bn_bwd_finalize: bad dims");
+    GN_PARTS_OK("bn_bwd_finalize");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, gamma, mean,
-                       invstd, (double)count, C, dgamma, dbeta, coef3);
+                       invstd, (double)count, nparts, C, dgamma, dbeta, coef3);
     GN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }
 
 int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
-                       float* dy, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream) {
+                       float* dy, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C, void* stream) {
     GN_REQUIRE(dz && p && idx && y && coef3 && dy && dbias_partials, GOALNET_E_NULL, "bnpool_bwd: null pointer");
+    GN_PARTS_OK("bnpool_bwd");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd: bad dims");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd: alignment");
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
-        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
                            dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
-        hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(PARTS), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
+        hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("bnpool_bwd");
@@ -490,15 +499,17 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
 }
 
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
-                             float* dy, void* dy_pad_bf16, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream) {
+                             float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                             void* stream) {
     GN_REQUIRE(dz && p && idx && y && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p: null pointer");
+    GN_PARTS_OK("bnpool_bwd_bf16p");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: bad dims (C %% 32)");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p: alignment");
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(PARTS * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
                        dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;

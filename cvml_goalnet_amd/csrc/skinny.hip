@@ -13,8 +13,8 @@ using namespace goalnet;
 
 namespace {
 
-constexpr int KT = 1024;     // forward: K-slab per block (x slab in LDS: MR x KT floats)
-constexpr int JB = 16;       // forward: output columns per block (4 per wave)
+constexpr int KT = 512;      // forward: K-slab per block (x slab in LDS: MR x KT floats = 24..32 KB -> 5..6 blocks per CU)
+constexpr int JB = 32;       // forward: output columns per block (two rounds of 4 per wave)
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -42,40 +42,48 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(&xs[m * KT + kq * 4]) = v;
     }
     __syncthreads();
-    const int j0 = blockIdx.x * JB + wv * 4;
-    float acc[4][MR];
+#pragma unroll 1
+    for (int rnd = 0; rnd < JB / 16; ++rnd) {
+        const int j0 = blockIdx.x * JB + rnd * 16 + wv * 4;
+        float acc[4][MR];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int m = 0; m < MR; ++m) acc[jj][m] = 0.f;
+            for (int m = 0; m < MR; ++m) acc[jj][m] = 0.f;
+        float4 w4[KT / 256][4];
 #pragma unroll
-    for (int kk = 0; kk < KT / 256; ++kk) {
-        const int kl = kk * 256 + lane * 4;
-        const int64_t k = k0 + kl;
-        float4 w4[4];
+        for (int kk = 0; kk < KT / 256; ++kk)         // all weight loads of the round are in flight before the first FMA
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = j0 + jj;
-            w4[jj] = (j < J && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                const int64_t k = k0 + kk * 256 + lane * 4;
+                w4[kk][jj] = (j < J && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const float4 x4 = *reinterpret_cast<const float4*>(&xs[m * KT + kl]);
+        for (int kk = 0; kk < KT / 256; ++kk) {
+            const int kl = kk * 256 + lane * 4;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[jj][m] += dot4(w4[jj], x4);
-        }
-    }
+            for (int m = 0; m < MR; ++m) {
+                const float4 x4 = *reinterpret_cast<const float4*>(&xs[m * KT + kl]);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const float v = wave_sum(acc[jj][m]);
-            const int j = j0 + jj;
-            if (lane == 0 && m < M && j < J) {
-                if (KS > 1) ep.out[(int64_t)blockIdx.y * ep.slab_stride + (int64_t)m * J + j] = v;
-                else ep.out[(int64_t)m * ep.ld + j] = epi_apply(ep, v, m, j);
+                for (int jj = 0; jj < 4; ++jj) acc[jj][m] += dot4(w4[kk][jj], x4);
             }
         }
+        // lane jj * MR + m keeps the total of (column j0 + jj, row m): one parallel epilogue instead of 4 * MR serial ones
+        float mine = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float v = wave_sum_dpp(acc[jj][m]);
+                if (lane == jj * MR + m) mine = v;
+            }
+        const int m = lane % MR, j = j0 + lane / MR;
+        if (lane < 4 * MR && m < M && j < J) {
+            if (KS > 1) ep.out[(int64_t)blockIdx.y * ep.slab_stride + (int64_t)m * J + j] = mine;
+            else ep.out[(int64_t)m * ep.ld + j] = epi_apply(ep, mine, m, j);
+        }
+    }
 }
 
 // ---- dX: dx[m][k] = (sum_j dy[m][j] w[j][k]) * mult[m][k]; grid ceil(K / 64); 16 j-groups x 16 k-float4 per block ----

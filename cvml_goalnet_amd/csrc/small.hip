@@ -13,40 +13,54 @@ using namespace goalnet;
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// Conv1d (kernel 3), NCL layout. One thread per output element.
+// Conv1d (kernel 3), NCL layout.
 // ---------------------------------------------------------------------------------------------
+// 16 lanes (one DPP row) per output element: the lanes split the input channels, row16_sum adds them in a fixed order.
 __global__ __launch_bounds__(256) void conv1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, int relu, float* __restrict__ y,
                                                         int N, int Cin, int L, int Cout, int Lo, int stride, int pad) {
     const int64_t total = (int64_t)N * Cout * Lo;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int lo = (int)(i % Lo);
-        const int co = (int)((i / Lo) % Cout);
-        const int64_t n = i / ((int64_t)Lo * Cout);
+    const int g = threadIdx.x & 15;
+    const int64_t step = (int64_t)gridDim.x * 16;
+    const int64_t rounds = (total + step - 1) / step;          // every lane runs the same number of rounds (DPP needs full rows)
+    int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    for (int64_t r = 0; r < rounds; ++r, i += step) {
+        const bool ok = i < total;
+        const int64_t ic = ok ? i : 0;
+        const int lo = (int)(ic % Lo);
+        const int co = (int)((ic / Lo) % Cout);
+        const int64_t n = ic / ((int64_t)Lo * Cout);
         const float* xs = x + n * Cin * L;
         const float* ws = w + (int64_t)co * Cin * 3;
-        float acc = b[co];
+        float acc = 0.f;
         const int l0 = stride * lo - pad;
-        for (int ci = 0; ci < Cin; ++ci) {
+        for (int ci = g; ci < Cin; ci += 16) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int l = l0 + k;
                 if ((unsigned)l < (unsigned)L) acc = fmaf(xs[ci * L + l], ws[ci * 3 + k], acc);
             }
         }
-        y[i] = relu ? fmaxf(acc, 0.f) : acc;
+        acc = row16_sum(acc) + b[co];
+        if (ok && g == 0) y[i] = relu ? fmaxf(acc, 0.f) : acc;
     }
 }
 
-// dx[n][ci][l] = sum_{co,k : stride*lo - pad + k = l} dz[n][co][lo] * w[co][ci][k]
+// dx[n][ci][l] = sum_{co,k : stride*lo - pad + k = l} dz[n][co][lo] * w[co][ci][k]; 16 lanes split the output channels
 __global__ __launch_bounds__(256) void conv1d_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                        float* __restrict__ dx, int N, int Cin, int L, int Cout, int Lo,
                                                        int stride, int pad) {
     const int64_t total = (int64_t)N * Cin * L;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int l = (int)(i % L);
-        const int ci = (int)((i / L) % Cin);
-        const int64_t n = i / ((int64_t)L * Cin);
+    const int g = threadIdx.x & 15;
+    const int64_t step = (int64_t)gridDim.x * 16;
+    const int64_t rounds = (total + step - 1) / step;
+    int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    for (int64_t r = 0; r < rounds; ++r, i += step) {
+        const bool ok = i < total;
+        const int64_t ic = ok ? i : 0;
+        const int l = (int)(ic % L);
+        const int ci = (int)((ic / L) % Cin);
+        const int64_t n = ic / ((int64_t)L * Cin);
         const float* dzs = dz + n * Cout * Lo;
         float acc = 0.f;
 #pragma unroll
@@ -55,9 +69,10 @@ __global__ __launch_bounds__(256) void conv1d_dx_kernel(const float* __restrict_
             if (t < 0 || t % stride != 0) continue;
             const int lo = t / stride;
             if (lo >= Lo) continue;
-            for (int co = 0; co < Cout; ++co) acc = fmaf(dzs[co * Lo + lo], w[((int64_t)co * Cin + ci) * 3 + k], acc);
+            for (int co = g; co < Cout; co += 16) acc = fmaf(dzs[co * Lo + lo], w[((int64_t)co * Cin + ci) * 3 + k], acc);
         }
-        dx[i] = acc;
+        acc = row16_sum(acc);
+        if (ok && g == 0) dx[i] = acc;
     }
 }
 
@@ -285,7 +300,7 @@ int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu,
     GN_REQUIRE(x && w && b && y, GOALNET_E_NULL, "conv1d_fwd: null pointer");
     GN_REQUIRE(N > 0 && Cin > 0 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE, "conv1d_fwd: bad dims");
     const int Lo = (L + 2 * pad - 3) / stride + 1;
-    hipLaunchKernelGGL(conv1d_fwd_kernel, dim3(grid1d((int64_t)N * Cout * Lo)), dim3(256), 0, (hipStream_t)stream, x, w, b, relu, y,
+    hipLaunchKernelGGL(conv1d_fwd_kernel, dim3(grid1d((int64_t)N * Cout * Lo * 16)), dim3(256), 0, (hipStream_t)stream, x, w, b, relu, y,
                        N, Cin, L, Cout, Lo, stride, pad);
     GN_LAUNCH_CHECK("conv1d_fwd");
     return 0;
@@ -298,7 +313,7 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
     const int Lo = (L + 2 * pad - 3) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
+        hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L * 16)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
         GN_LAUNCH_CHECK("conv1d_bwd.dx");
     }
     hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);

@@ -93,35 +93,47 @@ def conv1_wgrad(x_nchw, dy, dw, db, N, H, W):
                                     N, H, W, _s()), "conv1_wgrad")
 
 
+def stat_parts(units):
+    """rows of a partial-sum buffer for `units` independent work items (frames): min(units, STAT_PARTS)"""
+    return max(1, min(int(units), STAT_PARTS))
+
+
+def _rows(partials, width):
+    """the partial-sum kernels take the row count from the buffer the caller allocated: [nparts][width] doubles"""
+    assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() % width == 0
+    n = partials.numel() // width
+    assert 1 <= n <= STAT_PARTS, n
+    return n
+
+
 def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     _chk(y, p, idx, partials)
     assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
     assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
-    assert partials.dtype == torch.float64 and partials.numel() >= STAT_PARTS * 2 * C
-    check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), N, Hc, Wc, C, _s()),
-          "pool_bnstats_fwd")
+    check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
+                                         N, Hc, Wc, C, _s()), "pool_bnstats_fwd")
 
 
 def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mean, invstd, scale, shift):
     _chk(partials, gamma, beta, rmean, rvar, mean, invstd, scale, shift)
     for t in (gamma, beta, mean, invstd, scale, shift):
         assert t.numel() == C and t.is_contiguous()
-    check(lib().goalnet_bn_finalize(partials.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps,
+    check(lib().goalnet_bn_finalize(partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps,
                                     count, C, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _s()),
           "bn_finalize")
 
 
 def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
     _chk(dz, p, mean, invstd, partials)
-    assert dz.numel() == p.numel() == npix * C and partials.numel() >= STAT_PARTS * 2 * C
-    check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), npix, C,
-                                      _s()), "bn_bwd_reduce")
+    assert dz.numel() == p.numel() == npix * C
+    check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
+                                      _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce")
 
 
 def bn_bwd_finalize(partials, gamma, mean, invstd, count, C, dgamma, dbeta, coef3):
     _chk(partials, gamma, mean, invstd, dgamma, dbeta, coef3)
     assert coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C
-    check(lib().goalnet_bn_bwd_finalize(partials.data_ptr(), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), count, C,
+    check(lib().goalnet_bn_bwd_finalize(partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), count, C,
                                         dgamma.data_ptr(), dbeta.data_ptr(), coef3.data_ptr(), _s()), "bn_bwd_finalize")
 
 
@@ -129,16 +141,16 @@ def bnpool_bwd(dz, p, idx, y, coef3, dy, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, y, coef3, dy, dbias_partials)
     npool = N * (Hc - 2) * (Wc - 2) * C
     assert dz.numel() == p.numel() == idx.numel() == npool and y.numel() == dy.numel() == N * Hc * Wc * C
-    assert dbias_partials.dtype == torch.float64 and dbias_partials.numel() >= STAT_PARTS * C
     check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
-                                   dbias_partials.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd")
+                                   dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd")
 
 
 def bnpool_bwd_bf16p(dz, p, idx, y, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, y, coef3, dy, dypad, dbias_partials)
     assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
     check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), _p(dy),
-                                         dypad.data_ptr(), dbias_partials.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p")
+                                         dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
+          "bnpool_bwd_bf16p")
 
 
 def partials_sum(partials, nparts, stride, C, out):

@@ -39,8 +39,11 @@ extern "C" {
 #define GOALNET_E_ALIGN (-3)     /* pointer or leading dimension not 16-byte aligned */
 #define GOALNET_E_WORKSPACE (-4) /* workspace too small */
 
-/* number of per-block partial rows produced by the statistics kernels (fixed => deterministic sums) */
+/* upper bound of the per-block partial rows produced by the statistics kernels. The caller chooses nparts in
+ * [1, GOALNET_STAT_PARTS] (goalnet_stat_parts: one per frame, clamped) and passes the same value to the producer and to
+ * the kernel that sums the rows; for a given nparts the summation order is fixed => deterministic. */
 #define GOALNET_STAT_PARTS 1024
+int goalnet_stat_parts(int64_t units);
 
 int goalnet_abi_version(void);
 const char* goalnet_last_error(void);
@@ -67,29 +70,30 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
 
 /* ---- MaxPool2d(3,1,0) + train-mode BatchNorm statistics.  utils.py:153-154 (and 158-159, 163-164) */
 /* p = maxpool3x3s1(y); idx = argmax position 0..8 (first max in kh,kw scan order, as ATen);
- * partials[GOALNET_STAT_PARTS][2][C] (double) = per-block sum and sum of squares of p. */
-int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials,
+ * partials[nparts][2][C] (double) = per-block sum and sum of squares of p. */
+int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials, int nparts,
                              int N, int Hc, int Wc, int C, void* stream);
 /* mean/biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated
  * with `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
-int goalnet_bn_finalize(const double* partials, const float* gamma, const float* beta,
+int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int64_t count,
                         int C, float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* BatchNorm backward, phase 1: per-channel sum(dz) and sum(dz * xhat) -> partials (double). */
 int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
-                          double* partials, int64_t npix, int C, void* stream);
+                          double* partials, int nparts, int64_t npix, int C, void* stream);
 /* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
-int goalnet_bn_bwd_finalize(const double* partials, const float* gamma, const float* mean, const float* invstd,
+int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
 /* phase 3, fused: BN backward apply -> max-pool backward (gather by argmax) -> ReLU backward.
  * dy[N][Hc][Wc][C] = grad wrt the conv's pre-ReLU output; dbias_partials (double
- * [GOALNET_STAT_PARTS][C]) = per-block column sums of dy. */
+ * [nparts][C]) = per-block column sums of dy. */
 int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
-                       float* dy, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream);
+                       float* dy, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C, void* stream);
 /* same, writing dy as bf16 into the zero-padded layout of goalnet_to_bf16_padded (dy_pad_bf16 = padded pixel 0);
  * the fp32 dy is optional (NULL when only the bf16 GEMMs consume it). */
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
-                             float* dy, void* dy_pad_bf16, double* dbias_partials, int N, int Hc, int Wc, int C, void* stream);
+                             float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                             void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
 

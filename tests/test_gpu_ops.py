@@ -137,8 +137,10 @@ def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
     close(f"conv3x3_wgrad[{n}x{h}x{w}x{cin}->{cout}]", dw, ref.permute(0, 2, 3, 1), rtol=5e-6)
 
 
-@pytest.mark.parametrize("n,hc,wc,c", [(2, 15, 15, 64), (3, 13, 13, 256), (1, 11, 11, 512), (2, 3, 5, 64), (16, 11, 11, 512), (20, 13, 13, 256)])
-def test_pool_bn_forward_and_backward(n, hc, wc, c):
+@pytest.mark.parametrize("n,hc,wc,c,parts", [(2, 15, 15, 64, 0), (3, 13, 13, 256, 0), (1, 11, 11, 512, 0), (2, 3, 5, 64, 1024),
+                                              (16, 11, 11, 512, 5), (20, 13, 13, 256, 1024)])
+def test_pool_bn_forward_and_backward(n, hc, wc, c, parts):
+    parts = parts or ops.stat_parts(n)                # rows of the partial-sum buffers: one per frame / fewer / the maximum
     z = rnd(n, hc, wc, c, seed=16)
     y = F.relu(z)                                     # conv output after ReLU: many exact zeros (ties)
     gamma = rnd(c, seed=17, lo=0.5, hi=1.5)
@@ -160,7 +162,7 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c):
     yg = y.to(DEV)
     p = torch.empty(n, hp, wp, c, device=DEV)
     idx = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=DEV)
-    partials = torch.empty(ops.STAT_PARTS * 2 * c, dtype=torch.float64, device=DEV)
+    partials = torch.empty(parts * 2 * c, dtype=torch.float64, device=DEV)
     ops.pool_bnstats_fwd(yg, p, idx, partials, n, hc, wc, c)
     st = torch.empty(4, c, device=DEV)
     rmg, rvg = rm0.to(DEV), rv0.to(DEV)
@@ -189,9 +191,10 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c):
     dbeta = torch.empty(c, device=DEV)
     ops.bn_bwd_finalize(partials, gamma.to(DEV), st[0], st[1], n * hp * wp, c, dgamma, dbeta, coef3)
     dy = torch.empty(n, hc, wc, c, device=DEV)
-    ops.bnpool_bwd(dbn, p, idx, yg, coef3, dy, partials, n, hc, wc, c)
+    dparts = torch.empty(parts * c, dtype=torch.float64, device=DEV)
+    ops.bnpool_bwd(dbn, p, idx, yg, coef3, dy, dparts, n, hc, wc, c)
     dbias = torch.empty(c, device=DEV)
-    ops.partials_sum(partials, ops.STAT_PARTS, c, c, dbias)
+    ops.partials_sum(dparts, parts, c, c, dbias)
     close("bn.dgamma", dgamma, gd.grad, rtol=5e-6)
     close("bn.dbeta", dbeta, bd.grad, rtol=5e-6)
     close("block.dz (bn+pool+relu bwd)", dy, nhwc(zd.grad), rtol=1e-5)
