@@ -17,6 +17,13 @@ STAT_PARTS = 1024
 
 P = c_void_p  # device pointers and the stream travel as void*
 
+
+class RowCopy(ctypes.Structure):
+    """goalnet_rowcopy (include/goalnet_hip.h)"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_bytes", c_int64), ("nrows", c_int), ("gather", c_int), ("cursor", c_void_p),
+                ("cursor_bias", c_int64)]
+
+
 # name -> (restype, [argtypes])   — one row per entry point declared in include/goalnet_hip.h
 PROTOTYPES = {
     "goalnet_abi_version": (c_int, []),
@@ -70,7 +77,9 @@ PROTOTYPES = {
     "goalnet_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, P]),
     "goalnet_counter_add": (c_int, [P, c_int64, P]),
     "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, P]),
-    "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_float, P]),
+    "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
+    "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
+    "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
     "goalnet_rows_gather": (c_int, [P, P, c_int64, c_int, P, P]),
     "goalnet_rows_scatter": (c_int, [P, P, c_int64, c_int, P, P]),
 }

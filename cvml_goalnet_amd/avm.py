@@ -109,6 +109,8 @@ class AVM(nn.Module):
         self._hw3 = self._l2 = None
         self._adam_t = 0
         self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
+        self._defer_tick = False       # inside train_step: counters advance once, at the end (one launch)
+        self._pending_drop_tick = 0
         self._materialized = False
         self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
@@ -323,7 +325,10 @@ class AVM(nn.Module):
         widths = (512, 512, 512, 256, 128)
         buf = torch.empty(n * sum(widths), dtype=F32, device=self._device)
         out = ops.dropout_masks_dev(buf, n, widths, self.dropout_seed, TID_DROP, 8, self._state[1], DROP_P)
-        ops.counter_add(self._state[1], 1)
+        if self._defer_tick:
+            self._pending_drop_tick = 1          # train_step advances all counters in one launch at its end
+        else:
+            ops.counter_add(self._state[1], 1)
         self._drop_step += 1
         return out
 
@@ -362,7 +367,8 @@ class AVM(nn.Module):
         dev = self._device
         p = torch.empty(n, hc - 2, wc - 2, c, dtype=F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
-        partials = torch.empty(ops.stat_parts(n) * 2 * c, dtype=torch.float64, device=dev)     # one row per frame
+        # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
+        partials = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=dev)
         ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
         bn = getattr(self.visbl, f"bnorm{i}")
         st = torch.empty(4, c, dtype=F32, device=dev)
@@ -483,7 +489,7 @@ class AVM(nn.Module):
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
                             G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
-        dparts = torch.empty(ops.stat_parts(n) * c, dtype=torch.float64, device=dev)            # dbias partials, one row per frame
+        dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)        # dbias partials per (frame, row band)
         if self.precision == "bf16" and i > 1:
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
             dy = self._padbuf(f"dy{i}", n, hc, wc, c)
@@ -491,7 +497,7 @@ class AVM(nn.Module):
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
             ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, dparts, n, hc, wc, c)
-        ops.partials_sum(dparts, ops.stat_parts(n), c, c, G(f"visbl.conv{i}.bias"))
+        ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
         return dy
 
     def backward_device(self, ctx, dout, on_bucket=None):
@@ -644,9 +650,14 @@ class AVM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # device-resident fused train step: forward, broadcast MSE, backward, Adam
     # ------------------------------------------------------------------------------------------
-    def train_step(self, audio, visual, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        """main.py:187-193 on GPU tensors. Returns (loss (1,), pred (N,)) as GPU tensors, no host sync."""
-        out, ctx = self.forward_device(audio, visual, save=True)
+    def train_step(self, audio, visual, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, _loop_tick=(0, 0)):
+        """main.py:187-193 on GPU tensors. Returns (loss (1,), pred (N,)) as GPU tensors, no host sync.
+        `_loop_tick`: (frames, sub-batches) the caller's loop counters advance by (loop.VideoTrainer)."""
+        self._defer_tick, self._pending_drop_tick = True, 0
+        try:
+            out, ctx = self.forward_device(audio, visual, save=True)
+        finally:
+            self._defer_tick = False
         n = out.numel()
         loss = torch.empty(1, dtype=F32, device=self._device)
         dout = torch.empty(n, dtype=F32, device=self._device)
@@ -657,17 +668,21 @@ class AVM(nn.Module):
         scale = 1.0
         if sync is not None:
             scale = sync.finish(self)
-        self.adam_step(lr, betas, eps, scale)
+        self.adam_step(lr, betas, eps, scale, _tick=False)
+        ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
-        """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193)."""
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True):
+        """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
+        counter state[0] (= completed steps) + 1, so the same captured launch serves every step."""
         if self._adam_m is None:
             self._adam_m = torch.zeros_like(self._arena)
             self._adam_v = torch.zeros_like(self._arena)
         self._adam_t += 1
-        ops.counter_add(self._state[0], 1)
-        ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0], grad_scale)
+        ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
+                          grad_scale, step_bias=1)
+        if _tick:
+            ops.counter_add(self._state[0], 1)
 
     def grad_of(self, name) -> torch.Tensor:
         """Gradient of a parameter as a strided view with the reference's logical shape (linear5: (512, C*HW) copy)."""

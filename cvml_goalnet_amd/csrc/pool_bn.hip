@@ -267,23 +267,27 @@ __device__ __forceinline__ void slice_reduce_store(double (&v)[2][4], int nv, in
 
 __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* __restrict__ y, float* __restrict__ p,
                                                                  uint8_t* __restrict__ idx, double* __restrict__ partials,
-                                                                 int N, int Hc, int Wc, int C) {
+                                                                 int N, int Hc, int Wc, int C, int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][Wc][CS] floats (>= 16 KB for the reduction)
     const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
     const int ccn = C / CS;
     const int slot = blockIdx.x / ccn, c0 = (blockIdx.x % ccn) * CS + l8 * 4;
     const int Hp = Hc - 2, Wp = Wc - 2;
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int n = slot; n < N; n += (int)gridDim.x / ccn) {
+    // work unit = (frame, band of pooled rows): with few frames (the reference's 10-frame sub-batches) the bands give
+    // the grid its parallelism; a unit keeps three conv rows in LDS and rolls down its band
+    for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {
+        const int n = unit / bands, band = unit % bands;
+        const int p0 = (int)((int64_t)Hp * band / bands), p1 = (int)((int64_t)Hp * (band + 1) / bands);
         const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
         float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         uint8_t* in = idx ? idx + (int64_t)n * Hp * Wp * C + c0 : nullptr;
         __syncthreads();
-        for (int rr = 0; rr < 2; ++rr)
+        for (int rr = p0; rr < p0 + 2; ++rr)
             for (int x = px; x < Wc; x += 32)
-                *reinterpret_cast<float4*>(&smem[((rr * Wc) + x) * CS + l8 * 4]) =
+                *reinterpret_cast<float4*>(&smem[(((rr % 3) * Wc) + x) * CS + l8 * 4]) =
                     *reinterpret_cast<const float4*>(yn + ((int64_t)rr * Wc + x) * C);
-        for (int ph = 0; ph < Hp; ++ph) {
+        for (int ph = p0; ph < p1; ++ph) {
             const int rnew = ph + 2;
             for (int x = px; x < Wc; x += 32)
                 *reinterpret_cast<float4*>(&smem[(((rnew % 3) * Wc) + x) * CS + l8 * 4]) =
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
                                                            const uint8_t* __restrict__ idx, const float* __restrict__ y,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
                                                            __hip_bfloat16* __restrict__ dy_pad,
-                                                           double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
+                                                           double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C,
+                                                           int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // dp [3][Wp][CS] floats, then idx [3][Wp][CS] bytes
     const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
     const int ccn = C / CS;
@@ -342,7 +347,9 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
     const float4 cbv = *reinterpret_cast<const float4*>(coef3 + C + c0);
     const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + c0);
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int n = slot; n < N; n += (int)gridDim.x / ccn) {
+    for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {       // (frame, band of dy rows), as in the forward
+        const int n = unit / bands, band = unit % bands;
+        const int h0 = (int)((int64_t)Hc * band / bands), h1 = (int)((int64_t)Hc * (band + 1) / bands);
         const float* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
         const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + (int64_t)n * Hp * Wp * C + c0;
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
         float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
         __hip_bfloat16* dpn = dy_pad ? dy_pad + (int64_t)n * (Hc + 2) * (Wc + 2) * C + c0 : nullptr;
         __syncthreads();
-        for (int h = 0; h < Hc; ++h) {
+        for (int h = h0 > 2 ? h0 - 2 : 0; h < h1; ++h) {     // dy row h gathers from pooled rows h-2..h: two warm-up rows
             if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
                 for (int x = px; x < Wp; x += 32) {
                     const int64_t o = ((int64_t)h * Wp + x) * C;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
                 }
             }
             __syncthreads();
-            for (int w = px; w < Wc; w += 32) {
+            for (int w = px; w < Wc && h >= h0; w += 32) {
                 float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int dh = 0; dh < 3; ++dh) {
@@ -413,6 +420,13 @@ __global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restr
     if (c < C && threadIdx.x < 16) out[c] = (float)s;
 }
 
+// partial rows beyond one per frame are spent on row bands inside each frame (>= 3 rows per band)
+int row_bands(int nparts, int N, int rows) {
+    int b = nparts / N;
+    if (b > rows / 3) b = rows / 3;
+    return b < 1 ? 1 : b;
+}
+
 bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >> 2)) == 0; }
 
 }  // namespace
@@ -435,7 +449,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
         hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
-                           partials, N, Hc, Wc, C);
+                           partials, N, Hc, Wc, C, row_bands(nparts, N, Hc - 2));
     } else {
         hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     }
@@ -489,7 +503,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
         hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
-                           dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
+                           dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
@@ -510,7 +524,7 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
     hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
-                       dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+                       dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;
 }

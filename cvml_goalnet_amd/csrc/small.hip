@@ -260,7 +260,7 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t n, double lr, double beta1, double beta2,
                                                   float eps, const int64_t* __restrict__ step_dev, int64_t step_host, float gs) {
-    const double t = (double)(step_dev ? *step_dev : step_host);
+    const double t = (double)(step_dev ? *step_dev + step_host : step_host);       // device counter + bias, or the host count
     const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
     const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
@@ -397,9 +397,9 @@ int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, d
 }
 
 int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                          double eps, const int64_t* step, float grad_scale, void* stream) {
+                          double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* stream) {
     GN_REQUIRE(step, GOALNET_E_NULL, "adam_step_dev: null step counter");
-    return adam_launch("adam_step_dev", p, g, m, v, n, lr, beta1, beta2, eps, step, 0, grad_scale, stream);
+    return adam_launch("adam_step_dev", p, g, m, v, n, lr, beta1, beta2, eps, step, step_bias, grad_scale, stream);
 }
 
 }  // extern "C"

@@ -13,6 +13,21 @@ using namespace goalnet;
 namespace {
 
 __global__ void counter_add_kernel(int64_t* ctr, int64_t delta) { *ctr += delta; }
+__global__ void counters_add4_kernel(int64_t* ctr, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
+    const int i = threadIdx.x;
+    ctr[i] += i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3;
+}
+
+struct RowCopies { goalnet_rowcopy seg[GOALNET_ROWCOPY_MAX]; };
+
+// several gathers / scatters in one launch: blockIdx.y selects the segment
+__global__ __launch_bounds__(256) void rows_copy_batch_kernel(RowCopies rc) {
+    const goalnet_rowcopy sg = rc.seg[blockIdx.y];
+    const int64_t row_words = sg.row_bytes / 4, words = row_words * sg.nrows, base = (*sg.cursor + sg.cursor_bias) * row_words;
+    const uint32_t* s = (const uint32_t*)sg.src + (sg.gather ? base : 0);
+    uint32_t* d = (uint32_t*)sg.dst + (sg.gather ? 0 : base);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
 
 struct Widths { int w[8]; int64_t off[9]; };
 
@@ -54,6 +69,32 @@ int goalnet_counter_add(int64_t* counter, int64_t delta, void* stream) {
     GN_REQUIRE(counter, GOALNET_E_NULL, "counter_add: null pointer");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
     GN_LAUNCH_CHECK("counter_add");
+    return 0;
+}
+
+int goalnet_counters_add4(int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3, void* stream) {
+    GN_REQUIRE(counters, GOALNET_E_NULL, "counters_add4: null pointer");
+    hipLaunchKernelGGL(counters_add4_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, counters, d0, d1, d2, d3);
+    GN_LAUNCH_CHECK("counters_add4");
+    return 0;
+}
+
+int goalnet_rows_copy_batch(const goalnet_rowcopy* segs, int count, void* stream) {
+    GN_REQUIRE(segs, GOALNET_E_NULL, "rows_copy_batch: null pointer");
+    GN_REQUIRE(count >= 1 && count <= GOALNET_ROWCOPY_MAX, GOALNET_E_SHAPE, "rows_copy_batch: 1..%d segments", GOALNET_ROWCOPY_MAX);
+    RowCopies rc;
+    int64_t most = 0;
+    for (int i = 0; i < count; ++i) {
+        const goalnet_rowcopy& g = segs[i];
+        GN_REQUIRE(g.src && g.dst && g.cursor, GOALNET_E_NULL, "rows_copy_batch: null pointer in segment %d", i);
+        GN_REQUIRE(g.row_bytes > 0 && (g.row_bytes & 3) == 0 && g.nrows > 0, GOALNET_E_SHAPE,
+                   "rows_copy_batch: segment %d: rows must be a positive multiple of 4 bytes", i);
+        rc.seg[i] = g;
+        const int64_t words = g.row_bytes / 4 * g.nrows;
+        if (words > most) most = words;
+    }
+    hipLaunchKernelGGL(rows_copy_batch_kernel, dim3(grid1(most, 2048), (unsigned)count), dim3(256), 0, (hipStream_t)stream, rc);
+    GN_LAUNCH_CHECK("rows_copy_batch");
     return 0;
 }
 

@@ -11,8 +11,9 @@ step (`subbatch_loss.item()`, `subbatch_predictions.flatten().tolist()`), `/root
     batch_loss = batch_loss / iterations                            # main.py:203
 
 `VideoTrainer.train_video` is that loop with the video resident in HBM and ONE HIP-graph launch per sub-batch:
-the graph gathers rows [cursor, cursor+n) of the video, runs forward + broadcast MSE + backward + fused Adam
-(`AVM.train_step`), scatters the predictions and the loss into per-video device arrays and advances the cursor.
+the graph gathers rows [cursor, cursor+n) of the video (one launch), runs forward + broadcast MSE + backward + fused
+Adam (`AVM.train_step`, whose last launch advances all four counters) and scatters the predictions and the loss into
+per-video device arrays (one launch).
 Everything that changes between sub-batches (frame cursor, sub-batch index, Adam step count, dropout draw index)
 is a device counter (csrc/stepstate.hip), so the same graph is replayed for every full sub-batch; a shorter last
 sub-batch uses a second graph captured for its own size. The host reads results back once per video.
@@ -76,17 +77,16 @@ class VideoTrainer:
         hw, bins = self._key
         vis = torch.empty(n, 3, hw[0], hw[1], dtype=F32, device=dev)
         lab = torch.empty(n, dtype=F32, device=dev)
-        ops.rows_gather(self._vid, vis, n, st[2])
-        ops.rows_gather(self._lab, lab, n, st[2])
+        segs = [(self._vid, vis, n, st[2], 0, True), (self._lab, lab, n, st[2], 0, True)]
         aud = None
         if m.audio_included:
             aud = torch.empty(n, 30, bins, dtype=F32, device=dev)
-            ops.rows_gather(self._aud, aud, n, st[2])
-        loss, pred = m.train_step(aud, vis, lab, self.lr, self.betas, self.eps)
-        ops.rows_scatter(pred, self._pred, n, st[2])
-        ops.rows_scatter(loss, self._loss, 1, st[3])
-        ops.counter_add(st[2], n)
-        ops.counter_add(st[3], 1)
+            segs.append((self._aud, aud, n, st[2], 0, True))
+        ops.rows_copy_batch(segs)                                       # frames[a:b], labels[a:b], audios[a:b]
+        # train_step advances all four counters in its last launch: cursor += n, sub-batch index += 1
+        loss, pred = m.train_step(aud, vis, lab, self.lr, self.betas, self.eps, _loop_tick=(n, 1))
+        # predictions.extend(...), losses.append(...) at the positions the step started from
+        ops.rows_copy_batch([(self._pred, pred, n, st[2], -n, False), (self._loss, loss, 1, st[3], -1, False)])
 
     def _host_bookkeeping_after_replay(self):
         """What an eager train_step does on the host besides launching kernels."""

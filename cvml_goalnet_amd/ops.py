@@ -420,12 +420,32 @@ def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p):
     return out
 
 
-def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def counters_add4(counters, d0, d1, d2, d3):
+    assert counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous()
+    check(lib().goalnet_counters_add4(counters.data_ptr(), int(d0), int(d1), int(d2), int(d3), _s()), "counters_add4")
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_bias=0):
+    """Adam with the 1-based step count = *step + step_bias"""
     _chk(p, g, m, v)
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n
     check(lib().goalnet_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
-                                      grad_scale, _s()), "adam_step_dev")
+                                      int(step_bias), grad_scale, _s()), "adam_step_dev")
+
+
+def rows_copy_batch(segments):
+    """segments: up to 4 of (table, block, nrows, cursor, cursor_bias, gather); rows [cursor + bias, +nrows) of `table`
+    are read into (gather) or written from (scatter) `block`. One launch."""
+    arr = (_lib.RowCopy * len(segments))()
+    for k, (table, block, nrows, cursor, bias, gather) in enumerate(segments):
+        _chk(table, block)
+        assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+        row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
+        assert block.numel() * block.element_size() == row_bytes * nrows
+        src, dst = (table, block) if gather else (block, table)
+        arr[k] = _lib.RowCopy(src.data_ptr(), dst.data_ptr(), row_bytes, nrows, 1 if gather else 0, _ctr(cursor), int(bias))
+    check(lib().goalnet_rows_copy_batch(arr, len(segments), _s()), "rows_copy_batch")
 
 
 def rows_gather(table, block, nrows, cursor):

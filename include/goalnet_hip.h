@@ -204,17 +204,26 @@ int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, d
  * as one graph per sub-batch, the Adam step count, the dropout draw index and the frame cursor must be read from
  * device memory. All counters are int64 in device memory. */
 int goalnet_counter_add(int64_t* counter, int64_t delta, void* stream);
+/* counters[i] += d_i for four consecutive counters (adam step, dropout draw, frame cursor, sub-batch index): one launch */
+int goalnet_counters_add4(int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3, void* stream);
 /* `layers` masks back to back in dst: mask l is (n, widths[l]) row-major, drawn from stream
  * tid_base + tid_stride * (*step) + l — the same bits as goalnet_dropout_mask with that tensor_id. widths: host array. */
 int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, uint64_t seed, uint32_t tid_base,
                               uint32_t tid_stride, const int64_t* step, float p, void* stream);
-/* goalnet_adam_step with the 1-based step count read from *step */
+/* goalnet_adam_step with the 1-based step count = *step + step_bias (bias 1: the counter holds the completed steps) */
 int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                          double beta2, double eps, const int64_t* step, float grad_scale, void* stream);
+                          double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* stream);
 /* block[0:nrows] = table[*cursor : *cursor + nrows]  (batch_frames[a:b], main.py:181-184); row_bytes % 4 == 0 */
 int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 /* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */
 int goalnet_rows_scatter(const void* block, void* table, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
+/* up to GOALNET_ROWCOPY_MAX gathers (gather != 0: dst[0:nrows] = src[c : c + nrows]) and scatters
+ * (gather == 0: dst[c : c + nrows] = src[0:nrows]) in one launch; c = *cursor + cursor_bias */
+#define GOALNET_ROWCOPY_MAX 4
+typedef struct {
+    const void* src; void* dst; int64_t row_bytes; int nrows; int gather; const int64_t* cursor; int64_t cursor_bias;
+} goalnet_rowcopy;
+int goalnet_rows_copy_batch(const goalnet_rowcopy* segs, int count, void* stream);
 
 #ifdef __cplusplus
 }

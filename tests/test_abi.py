@@ -41,7 +41,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.goalnet_conv3x3_fwd_ws_bytes(10, 11, 11, 256, 512) > 0
     assert lib.goalnet_conv3x3_fwd_ws_bytes(1024, 72, 72, 256, 512) == 0
     assert lib.goalnet_conv3x3_fwd_bf16p_ws_bytes(1024, 72, 72, 256, 512) == 0
-    rc = lib.goalnet_adam_step_dev(16, 16, 16, 16, 4, 1e-3, 0.9, 0.999, 1e-8, None, 1.0, None)
+    rc = lib.goalnet_adam_step_dev(16, 16, 16, 16, 4, 1e-3, 0.9, 0.999, 1e-8, None, 1, 1.0, None)
     assert rc == -1 and b"step counter" in lib.goalnet_last_error()
     rc = lib.goalnet_rows_gather(16, 16, 6, 1, 16, None)
     assert rc == -2 and b"multiple of 4" in lib.goalnet_last_error()

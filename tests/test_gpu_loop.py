@@ -70,6 +70,20 @@ def test_device_counter_kernels_match_their_host_scalar_twins():
     vec = torch.zeros(20, dtype=torch.float32, device=dev)
     ops.rows_scatter(torch.tensor([7.0], device=dev), vec, 1, cur[0])
     assert vec[4] == 7 and vec.sum() == 7
+    # several segments in one launch, with a cursor bias; four counters in one launch
+    blk2 = torch.empty(3, 2, 3, dtype=torch.float32, device=dev)
+    vec2 = torch.zeros(20, dtype=torch.float32, device=dev)
+    ops.rows_copy_batch([(table, blk2, 3, cur[0], 2, True), (vec2, torch.tensor([1.0, 2.0], device=dev), 2, cur[0], -4, False)])
+    assert torch.equal(blk2, table[6:9]) and vec2[0] == 1 and vec2[1] == 2 and vec2.sum() == 3
+    ops.counters_add4(ctr, 1, 2, 3, -4)
+    assert ctr.tolist() == [1, 5, 3, -4]
+    # Adam with a step bias: counter holds the completed steps
+    t0 = torch.tensor([2], dtype=torch.int64, device=dev)
+    pc, mc, vc = p0.clone(), torch.zeros(cnt, device=dev), torch.zeros(cnt, device=dev)
+    pd, md, vd = p0.clone(), torch.zeros(cnt, device=dev), torch.zeros(cnt, device=dev)
+    ops.adam_step(pc, gr, mc, vc, LR, 0.9, 0.999, 1e-8, 3, 1.0)
+    ops.adam_step_dev(pd, gr, md, vd, LR, 0.9, 0.999, 1e-8, t0[0], 1.0, step_bias=1)
+    assert torch.equal(pc, pd)
 
 
 def _video(n, h, audio, salt):

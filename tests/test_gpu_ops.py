@@ -138,9 +138,10 @@ def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
 
 
 @pytest.mark.parametrize("n,hc,wc,c,parts", [(2, 15, 15, 64, 0), (3, 13, 13, 256, 0), (1, 11, 11, 512, 0), (2, 3, 5, 64, 1024),
-                                              (16, 11, 11, 512, 5), (20, 13, 13, 256, 1024)])
+                                              (16, 11, 11, 512, 5), (20, 13, 13, 256, 1024), (3, 15, 13, 64, 12), (2, 76, 9, 64, 37),
+                                              (10, 11, 11, 512, 80)])
 def test_pool_bn_forward_and_backward(n, hc, wc, c, parts):
-    parts = parts or ops.stat_parts(n)                # rows of the partial-sum buffers: one per frame / fewer / the maximum
+    parts = parts or ops.stat_parts(n)                # partial rows: one per frame / fewer / several row bands per frame
     z = rnd(n, hc, wc, c, seed=16)
     y = F.relu(z)                                     # conv output after ReLU: many exact zeros (ties)
     gamma = rnd(c, seed=17, lo=0.5, hi=1.5)
