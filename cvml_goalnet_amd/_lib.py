@@ -80,6 +80,11 @@ PROTOTYPES = {
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
+    "goalnet_knapsack_ws_bytes": (c_size_t, [c_int, c_int]),
+    "goalnet_knapsack": (c_int, [P, P, c_int, c_int, P, P, c_size_t, P]),
+    "goalnet_fscore": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "goalnet_postprocess_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "goalnet_postprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, c_size_t, P]),
     "goalnet_rows_gather": (c_int, [P, P, c_int64, c_int, P, P]),
     "goalnet_rows_scatter": (c_int, [P, P, c_int64, c_int, P, P]),
 }

@@ -217,6 +217,30 @@ int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t 
 int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 /* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */
 int goalnet_rows_scatter(const void* block, void* table, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
+/* ---- after the hot path, once per video: summary selection and F-score.  utils.py:586-643 -------------------
+ * Integer work, bit-exact with the reference's Python (DESIGN.md "post-processing"). All pointers are device memory. */
+/* 0/1 knapsack of utils.py:465-510 on already scaled integer weights (int(w * scale_factor)) and capacity
+ * (int(capacity * scale_factor)); selected[i] = 1 for the items the reference's back-tracking returns. */
+size_t goalnet_knapsack_ws_bytes(int n_items, int capacity_scaled);
+int goalnet_knapsack(const int64_t* values, const int32_t* weights_scaled, int n_items, int capacity_scaled,
+                     int32_t* selected, void* ws, size_t ws_bytes, void* stream);
+/* get_fscore, utils.py:552-580: gd [n_users][full_n_frames] and mask [full_n_frames] hold 0/1; fscore[0] = mean,
+ * fscore[1] = max over the users; counts: scratch of 2 * (n_users + 1) int64 (exact integer sums) */
+int goalnet_fscore(const uint8_t* gd, const uint8_t* mask, int n_users, int full_n_frames, double* fscore, int64_t* counts,
+                   void* stream);
+/* postprocess (utils.py:606-643) [+ get_fscore when gd != NULL]: pred = the model's N_sampled outputs; importances =
+ * int8(round half even), expanded x skip_frames to full_n_frames (expand_array, utils.py:396-410); per clip
+ * value = sum over [a:b), length = len([a:b)) (utils.py:445-463), weight = length * weight_scale; knapsack with
+ * capacity_scaled = int(int(0.15 * full_n_frames) * 5) computed by the caller (utils.py:633, 478); mask[a..b] = 1 for
+ * the selected clips (end inclusive, utils.py:637-641). status[0] != 0: a selected interval leaves the video (the
+ * reference raises IndexError there). Outputs: mask [full_n_frames], selected [n_clips] flags, clip_values [n_clips],
+ * clip_lengths [n_clips], fscore [2], status [1]. */
+size_t goalnet_postprocess_ws_bytes(int n_clips, int capacity_scaled, int n_users);
+int goalnet_postprocess(const float* pred, int n_sampled, int skip_frames, int full_n_frames, const int32_t* change_points,
+                        int n_clips, int weight_scale, int capacity_scaled, const uint8_t* gd, int n_users, uint8_t* mask,
+                        int32_t* selected, int64_t* clip_values, int32_t* clip_lengths, double* fscore, int32_t* status,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* up to GOALNET_ROWCOPY_MAX gathers (gather != 0: dst[0:nrows] = src[c : c + nrows]) and scatters
  * (gather == 0: dst[c : c + nrows] = src[0:nrows]) in one launch; c = *cursor + cursor_bias */
 #define GOALNET_ROWCOPY_MAX 4

@@ -75,3 +75,14 @@ class Golden:
 GOLDEN_CASES_SMALL = ["avm_a1_n10_h40_p0", "avm_a1_n10_h40_mask3", "avm_a0_n10_h40_mask", "avm_a1_n1_h40_p0",
                       "avm_a1_n16_h40_mask", "avm_a0_n7_h52_p0"]
 GOLDEN_CASES_BIG = ["avm_a1_n2_h224_p0"]
+
+
+POSTPROC_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("postproc_") and f.endswith(".npz"))
+
+
+def load_postproc(name):
+    """tests/golden/postproc_*.npz (written by make_golden_postproc.py from the reference's own functions): inputs
+    pred (N,1), change_points (n_clips,2), gd (20,N_raw), skip, full_n; outputs importances, expanded, clip_values,
+    clip_lengths, capacity, selected, mask, fscore."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}

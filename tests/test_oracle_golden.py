@@ -54,3 +54,40 @@ def test_macs_table_matches_survey():
     assert m224["total"] == 8_218_418_688
     assert m40["conv1"] + m40["conv2"] + m40["conv3"] == 168_046_272
     assert m224["conv1"] + m224["conv2"] + m224["conv3"] == 6_932_745_216
+
+
+# ---- post-processing: integer work, bit-exact -----------------------------------------------------
+from _golden import POSTPROC_CASES, load_postproc  # noqa: E402
+from oracle import postproc_ref  # noqa: E402
+
+
+@pytest.mark.parametrize("case", POSTPROC_CASES)
+def test_postproc_oracle_matches_reference_goldens_bit_for_bit(case):
+    z = load_postproc(case)
+    skip, full_n = int(z["skip"][0]), int(z["full_n"][0])
+    imp = postproc_ref.round_importances(z["pred"])
+    assert imp == z["importances"].tolist()
+    exp = postproc_ref.expand_array(imp, skip, full_n)
+    assert exp == z["expanded"].tolist()
+    vals, lens = postproc_ref.get_clip_information(z["change_points"], exp)
+    assert vals == z["clip_values"].tolist() and lens == z["clip_lengths"].tolist()
+    assert int(0.15 * full_n) == int(z["capacity"][0])
+    assert postproc_ref.knapsack(vals, lens, int(z["capacity"][0])) == z["selected"].tolist()
+    sel, mask = postproc_ref.postprocess(z["pred"], z["change_points"], skip, full_n)
+    assert sel == z["selected"].tolist() and np.array_equal(mask, z["mask"])
+    fa, fm = postproc_ref.postprocess_and_get_fscores(z["pred"], z["change_points"], z["gd"], skip, full_n)
+    assert [float(fa), float(fm)] == z["fscore"].tolist()           # the same doubles, not approximately
+
+
+def test_postproc_quirks_are_reproduced():
+    """end-exclusive sums vs end-inclusive mask; half-to-even rounding; IndexError past the end"""
+    cps = np.array([[0, 4], [5, 9]], dtype=np.int32)
+    vals, lens = postproc_ref.get_clip_information(cps, [1] * 10)
+    assert vals == [4, 4] and lens == [4, 4]                          # frames 4 and 9 are not counted ...
+    assert postproc_ref.summary_mask(cps, [0], 10).tolist() == [1, 1, 1, 1, 1, 0, 0, 0, 0, 0]   # ... but frame 4 is shown
+    assert postproc_ref.round_importances(np.array([1.5, 2.5, 3.5, 4.5], dtype=np.float32)) == [2, 2, 4, 4]
+    with pytest.raises(IndexError):
+        postproc_ref.summary_mask(np.array([[6, 10]]), [0], 10)
+    assert postproc_ref.expand_array([1, 2], 3, 8) == [1, 1, 1, 2, 2, 2, 2, 2]
+    assert postproc_ref.expand_array([1, 2, 3], 3, 5) == [1, 1, 1, 2, 2]
+    assert postproc_ref.expand_array([7, 8], 3, 2) == [7, 8]
