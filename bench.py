@@ -18,7 +18,11 @@ Extra objects on the JSON line:
                 inside the timed steps; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
   cpu_baseline  the oracle (CPU restatement of the reference, oracle/avm_ref.py) timed on this host's cores on a
                 bounded sample (1 clip = 16 frames of 224x224 per step), rank 0, N = 1 only.
-  parity        logit MAE / max-abs of the HIP forward vs that CPU reference on the same 16 frames and weights.
+  parity        logit MAE / max-abs of the HIP forward vs that CPU reference on the same 16 frames and weights: on the
+                random-init weights before the first optimizer step, and again on the weights the timed steps left.
+  native_40x40_loop  SURVEY.md §8(d) "report additionally frames/s at the reference-native 40x40": the reference's own
+                operating point (main.py:169-198: one video at a time, 10 frames per optimizer step, fp32), run by
+                loop.VideoTrainer as one HIP-graph launch per sub-batch; N = 1 only, a few seconds.
 """
 from __future__ import annotations
 
@@ -57,18 +61,22 @@ def make_inputs(n, h, w, device, seed):
     return aud, vis, lab
 
 
-def cpu_baseline_and_parity(model, h, w, seed, max_seconds=40.0):
-    """Time the oracle's train step on the host cores (bounded sample) and compare logits on the same inputs."""
+def logit_parity(model, h, w, seed):
+    """Logits of the HIP forward vs the CPU oracle on the same 16 frames, weights and dropout masks (regenerated from the
+    seed formula on both sides); BatchNorm in train mode. The probe restores the model's BatchNorm buffers."""
     from cvml_goalnet_amd import synth
     from oracle import avm_ref
     n = FRAMES_PER_CLIP
-    threads = torch.get_num_threads()
+    aud, vis, lab = make_inputs(n, h, w, model._device, seed + 1)
+    if not model._materialized:
+        with torch.no_grad():
+            model.forward_device(aud, vis, save=False)               # Lazy parameters take their random init here
+        for i in (1, 2, 3):                                          # ... and the buffers go back to their initial state
+            bn = getattr(model.visbl, f"bnorm{i}")
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
     sd = model.state_dict()                                          # torch-native layouts, CPU
     p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
     b = {k: v.clone() for k, v in sd.items() if k not in p}
-    aud, vis, lab = make_inputs(n, h, w, model._device, seed + 1)
-    a_c, v_c, l_c = aud.cpu(), vis.cpu(), lab.cpu()
-    # parity: forward with dropout masks regenerated from the seed formula on both sides
     step = model._drop_step
     masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, seed=model.dropout_seed, step=step)]
     bn_backup = {k: getattr(*model._module_of(k)).clone() for k in b}
@@ -79,11 +87,26 @@ def cpu_baseline_and_parity(model, h, w, seed, max_seconds=40.0):
         getattr(*model._module_of(k)).copy_(v)
     inter = {}
     with torch.no_grad():
-        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, a_c, v_c, masks, model.audio_included, inter)
+        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, aud.cpu(), vis.cpu(), masks, model.audio_included, inter)
     ref_logit = inter["logit"].view(-1)
-    mae = (hip_logit - ref_logit).abs().mean().item()
-    mx = (hip_logit - ref_logit).abs().max().item()
-    # timing: train steps of one clip (the Adam state allocation of the first step is the warm-up)
+    d = (hip_logit - ref_logit).abs()
+    return {"logit_mae_vs_cpu_ref": d.mean().item(), "logit_maxabs_vs_cpu_ref": d.max().item(),
+            "max_abs_logit": ref_logit.abs().max().item(), "frames": n}
+
+
+def cpu_baseline(model, h, w, seed, max_seconds=40.0):
+    """Time the oracle's train step on the host cores (bounded sample: one clip per step)."""
+    from cvml_goalnet_amd import synth
+    from oracle import avm_ref
+    n = FRAMES_PER_CLIP
+    threads = torch.get_num_threads()
+    sd = model.state_dict()
+    p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    b = {k: v.clone() for k, v in sd.items() if k not in p}
+    aud, vis, lab = make_inputs(n, h, w, model._device, seed + 1)
+    a_c, v_c, l_c = aud.cpu(), vis.cpu(), lab.cpu()
+    masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, seed=model.dropout_seed, step=0)]
+    # train steps of one clip (the Adam state allocation of the first step is the warm-up)
     state = {}
     times = []
     t_begin = time.time()
@@ -94,11 +117,32 @@ def cpu_baseline_and_parity(model, h, w, seed, max_seconds=40.0):
         if time.time() - t_begin > max_seconds:
             break
     t = min(times[1:]) if len(times) > 1 else times[0]
-    base = {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
+    return {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"oracle train step (fwd+MSE+bwd+Adam) on {n} frames (1 clip) of {h}x{w}, fp32, torch {torch.__version__} CPU, "
                       f"{len(times)} steps, best of the non-first: {t:.2f} s/step"}
-    par = {"logit_mae_vs_cpu_ref": mae, "logit_maxabs_vs_cpu_ref": mx, "frames": n, "dropout": "masks from seed formula", "bn": "train"}
-    return base, par
+
+
+def native40_loop(dev, frames=300, videos=3):
+    """The reference's loop at its native size: 40x40 frames, sub-batches of 10, fp32, audio on (main.py:44-46, 169-198)."""
+    from cvml_goalnet_amd import AVM, synth
+    from cvml_goalnet_amd.loop import VideoTrainer
+    vis = torch.from_numpy(synth.make_visual(frames, 40, 40)).to(dev)
+    aud = torch.from_numpy(synth.make_audio(frames)).to(dev)
+    lab = torch.from_numpy(synth.make_labels(frames)).to(dev)
+    model = AVM(audio_included=True, device=dev, precision="fp32")
+    tr = VideoTrainer(model, subbatch_size=10)
+    tr.train_video(aud, vis, lab)                       # warm-up video: first step eager, graph captured at the second
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(videos):
+        losses, preds = tr.train_video(aud, vis, lab)
+        batch_loss = losses.mean().item()               # the one host read-back per video (main.py:203)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = videos * ((frames + 9) // 10)
+    return {"frames_per_s": videos * frames / dt, "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
+            "dtype": "f32", "mode": "one HIP graph launch per sub-batch (loop.VideoTrainer)", "graph_replays": tr.replays,
+            "eager_steps": tr.eager_steps, "videos": videos, "frames_per_video": frames, "last_batch_loss": batch_loss}
 
 
 def main():
@@ -110,6 +154,7 @@ def main():
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true")
+    ap.add_argument("--no-native40", action="store_true", help="skip the extra 40x40 / 10-frame loop measurement")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "bf16"),
                     help="bf16 (default) = bf16-MFMA contractions with fp32 accumulation/statistics/master weights, logits within "
                          "the north star's 1e-3 of the fp32 CPU reference; f32 = the reference's arithmetic on the fp32 matrix cores")
@@ -152,6 +197,14 @@ def main():
     if distributed:
         model.grad_sync = GradSync(compress="bf16" if args.dtype == "bf16" else None)
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            parity = logit_parity(model, h, w, synth.BASE_SEED)     # on the random-init weights, before any optimizer step
+            parity.update({"weights": "random init (before the first optimizer step)", "dropout": "masks from seed formula", "bn": "train"})
+        except Exception as e:
+            log(f"parity probe failed: {e!r}")
+        torch.cuda.empty_cache()            # the probe's 16-frame buffers must not fragment the pool the 1024-frame steps use
     for _ in range(args.warmup):
         model.train_step(aud, vis, lab)
     model.kernel_events = {}
@@ -216,12 +269,22 @@ def main():
             res["other_kernels"] = others
         if world == 1 and not args.no_cpu_baseline:
             try:
-                base, par = cpu_baseline_and_parity(model, h, w, synth.BASE_SEED)
-                res["cpu_baseline"] = base
-                res["parity"] = par
+                if parity is not None:
+                    after = logit_parity(model, h, w, synth.BASE_SEED)
+                    parity[f"after_{args.warmup + args.steps}_adam_steps"] = after      # same probe on the trained weights
+                res["parity"] = parity
+                res["cpu_baseline"] = cpu_baseline(model, h, w, synth.BASE_SEED)
             except Exception as e:  # the bench line must still be printed
                 log(f"cpu_baseline failed: {e!r}")
                 res["cpu_baseline"] = None
+        if world == 1 and not args.no_native40:
+            try:
+                del model, aud, vis, lab
+                torch.cuda.empty_cache()
+                res["native_40x40_loop"] = native40_loop(dev)
+            except Exception as e:
+                log(f"native 40x40 loop failed: {e!r}")
+                res["native_40x40_loop"] = None
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)

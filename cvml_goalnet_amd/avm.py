@@ -25,6 +25,7 @@ the broadcast MSE, backward, (optional) gradient all-reduce and the fused Adam w
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -433,7 +434,7 @@ class AVM(nn.Module):
         k5 = 512 * hp3 * wp3
         # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
         # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
-        bf5 = bf and n > 16
+        bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
         if bf5:
             xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
             w5b = ops.cast_bf16(P("visbl.linear5.weight"), torch.empty(512 * k5, dtype=BF16, device=dev))
