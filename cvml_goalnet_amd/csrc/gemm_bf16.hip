@@ -16,35 +16,13 @@
 // (`buffer_load_dwordx4 ... lds`, 1 KB per wave-instruction, swizzle applied on the source address; zero padding and
 // rows past the end come from the buffer range check) into a 2-deep ring: at bf16 rates there is no VALU / VGPR
 // budget for a register round trip.
-#include <hip/hip_bf16.h>
-
-#include "gemm_common.h"
+#include "gemm_bf16_common.h"
 
 using namespace goalnet;
 
 namespace {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
 constexpr int BM = GEMM_BM, BN = GEMM_BN;
-constexpr int BKH = 64;                 // bf16 elements per K-tile (128 B per row)
-constexpr int ROWB = 128;               // bytes per LDS row
-constexpr int OP_BYTES = BM * ROWB;     // 16 KB per operand per stage
-constexpr unsigned OOB = 0xFFFFFF00u;
-
-__device__ __forceinline__ int kc_boff(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ uint32_t clamp_u32(int64_t v) {
-    return v <= 0 ? 0u : (v > 0xFFFFFF00ll ? 0xFFFFFF00u : (uint32_t)v);
-}
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_dst, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, (int)voff, (int)soff, 0, 0);
-}
 
 // ---- loaders (LDS-DMA). One wave-instruction fills 8 rows x 128 B; wave w issues pieces 4w .. 4w+3 of a tile. -----
 // K-contiguous bf16 matrix X[rows][K] (leading dim ld elements).
@@ -576,6 +554,13 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
     KCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, (int64_t)9 * Cin, Cout};
     const EpiP efinal{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
     EpiP ep = efinal;
+    // large problems: the 256 x 256 phased tile (gemm_bf16_256.hip); GOALNET_BF16_TILE=128 / 256 forces a choice (tests, A/B runs)
+    {
+        const char* forced = getenv("GOALNET_BF16_TILE");
+        const bool big = forced ? forced[0] == '2' : (Cout >= 256 && M >= 65536);
+        if (big) return launch_conv_bf16_256("conv3x3_fwd_bf16p(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M,
+                                             (const __hip_bfloat16*)w_bf16, Cout, efinal, st);
+    }
     const int nsplit = ws ? conv_splits_h(M, Cin, Cout) : 1;
     if (nsplit > 1) {
         GN_REQUIRE(aligned16(ws) && ws_bytes >= goalnet_conv3x3_fwd_bf16p_ws_bytes(N, H, W, Cin, Cout), GOALNET_E_WORKSPACE,

@@ -1,0 +1,35 @@
+// Pieces shared by the bf16 GEMM engines (gemm_bf16.hip: 128 x 128 tile, gemm_bf16_256.hip: 256 x 256 phased tile):
+// vector types, the swizzled K-contiguous LDS row image, buffer resources and the LDS-DMA primitive.
+#pragma once
+#include <hip/hip_bf16.h>
+
+#include "gemm_common.h"
+
+namespace goalnet {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int BKH = 64;                 // bf16 elements per K-tile (128 B per row)
+constexpr int ROWB = 128;               // bytes per LDS row
+constexpr int OP_BYTES = GEMM_BM * ROWB; // 16 KB: 128 rows of one operand
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+__device__ __forceinline__ int kc_boff(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t clamp_u32(int64_t v) {
+    return v <= 0 ? 0u : (v > 0xFFFFFF00ll ? 0xFFFFFF00u : (uint32_t)v);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+}
+
+// implemented in gemm_bf16_256.hip: conv 3x3 on zero-padded bf16 activations with the 256 x 256 phased tile
+int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
+                         int Cout, const EpiP& ep, hipStream_t st);
+
+}  // namespace goalnet
