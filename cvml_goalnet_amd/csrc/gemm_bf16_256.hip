@@ -20,7 +20,8 @@
 // Hazards (P = phase index, both groups; barriers are whole-block):
 //   RAW  a half-tile issued for K-tile t+2 is retired by the vmcnt(6) of phase (t+1, q3), placed BEFORE that phase's
 //        first barrier; its first ds_read is in phase (t+2, q0), i.e. after a barrier every waiter has passed — also
-//        for the staggered group.
+//        for the staggered group. B0 of K-tile t+1 is read one phase early (in (t, q3), to balance the LDS reads) and
+//        is retired by an extra vmcnt(8) in (t, q2).
 //   WAR  a slot read in phase P is restaged in phase P+1: the readers' lgkmcnt(0) sits before the first barrier of
 //        phase P, which both groups pass before anyone issues phase P+1's DMA.
 // Staging order (slot freed one phase earlier): (t,q0) A1 of t+1 | (t,q1) A0 of t+2 | (t,q2) B0 of t+2 | (t,q3) B1 of t+2.
@@ -75,9 +76,10 @@ struct ConvAPadLoader256 {
     struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; };
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
-    int Wp2, C, wave;
+    int Wp2, C, lgC, wave;
     __device__ ConvAPadLoader256(const P& p, int row0, int tid) {
         Wp2 = p.W + 2; C = p.C;
+        lgC = (p.C & (p.C - 1)) == 0 ? 31 - __builtin_clz(p.C) : -1;       // channel counts here are powers of two: no division per K-tile
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
         const int hw = p.H * p.W;
@@ -105,9 +107,9 @@ struct ConvAPadLoader256 {
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
         const int k = kt * BKH;
-        const int tap = k / C;
+        const int tap = lgC >= 0 ? k >> lgC : k / C;
         const int ci = k - tap * C;
-        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                  // tap / 3 for tap < 16
         // past the last K-tile (tap >= 9) the offset only has to stay harmless: the range check turns it into zeros
         const unsigned s0 = tap < 9 ? (unsigned)(((kh * Wp2 + kw) * C + ci) * 2) : OOB;
 #pragma unroll
@@ -119,19 +121,22 @@ __device__ __forceinline__ bf16x8 read_frag(const char* half, int row0, int ks, 
     return *reinterpret_cast<const bf16x8*>(half + kc_boff(row0 + (lane & 31), 2 * ks + (lane >> 5)));
 }
 
-// The compiler may move MFMAs (pure register operations) across a barrier builtin, which collapses the phase structure
-// (seen in the ISA: 4 / 3 / 17 / 8 MFMAs per phase instead of 8 each). The barriers are therefore `asm volatile` with a
-// memory clobber (pins ds_reads and the DMA), and the two accumulators of a phase pass through empty asm statements right
-// after the first barrier and right before the second: their MFMAs cannot be scheduled outside that window.
-#define GN_FENCE2(X, Y) asm volatile("" : "+v"(X), "+v"(Y))
+// The compiler may move MFMA builtins (pure register operations) across a barrier builtin, which collapses the phase
+// structure (seen in the ISA: 4 / 3 / 17 / 8 MFMAs per phase instead of 8 each); pinning them with data dependencies on
+// the accumulators would make every wave wait for its last MFMA to COMPLETE before it reaches the barrier (+70..100
+// cycles per phase). The MFMAs and the barriers are therefore `asm volatile`: issued exactly where written, and a wave
+// reaches the closing barrier while its last MFMAs drain. Hazards the compiler no longer covers are handled here:
+// accumulating back to back into the same registers needs no wait states (CDNA3/4 ISA, XDL write -> XDL SrcC, same
+// vDst); the epilogue reads the accumulators only after an explicit drain (s_nop block after the loop).
+__device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
 #define GN_PHASE(ACC0, ACC1, AF, BF)                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_setprio 1" ::: "memory");                         \
-    GN_FENCE2(ACC0, ACC1);                                                                                  \
+    asm volatile("s_barrier\n\ts_setprio 1" ::: "memory");                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
-        ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[0][ks], BF[ks], ACC0, 0, 0, 0);                   \
-        ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[1][ks], BF[ks], ACC1, 0, 0, 0);                   \
+        mfma_pinned(ACC0, AF[0][ks], BF[ks]);                                                               \
+        mfma_pinned(ACC1, AF[1][ks], BF[ks]);                                                               \
     }                                                                                                       \
-    GN_FENCE2(ACC0, ACC1);                                                                                  \
     asm volatile("s_setprio 0\n\ts_barrier" ::: "memory");
 
 template <class AL, class BL>
@@ -158,46 +163,55 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 
     // prologue: K-tile 0 complete, K-tile 1 without its A1 (phase (0,q0) stages that)
     al.issue(0, 0, slot(0, 0)); bl.issue(0, 0, slot(0, 2)); bl.issue(0, 1, slot(0, 3)); al.issue(0, 1, slot(0, 1));
-    al.issue(1, 0, slot(1, 0)); bl.issue(1, 0, slot(1, 2)); bl.issue(1, 1, slot(1, 3));
+    bl.issue(1, 0, slot(1, 2)); al.issue(1, 0, slot(1, 0)); bl.issue(1, 1, slot(1, 3));
     asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     if (wr == 1) asm volatile("s_barrier" ::: "memory");                 // stagger the two wave rows by one barrier
 
-    bf16x8 a[2][4], b0[4], b1[4];
+    // fragment registers: a = the current A half; bx / by = B0 / B1 of even K-tiles and B1 / B0 of odd ones: the B0
+    // fragments of the NEXT K-tile are read in phase q3 into the registers B1 has just left, so every phase issues at most
+    // 8 ds_read_b128 per wave (8 | 4 | 8 | 4) and the LDS time of a phase stays within one MFMA section.
+    bf16x8 a[2][4], bx[4], by[4];
     const int arow = wr * 64, brow = wc * 32;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bx[ks] = read_frag(slot(0, 2), brow, ks, lane);
+
+#define GN_KTILE(TT, B0R, B1R)                                                                              \
+    {                                                                                                       \
+        const int t_ = (TT);                                                                                \
+        /* q0: (A0, B0) */                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = read_frag(slot(t_, 0), arow + f * 32, ks, lane); \
+        al.issue(t_ + 1, 1, slot(t_ + 1, 1));                                                               \
+        GN_PHASE(acc[0][0], acc[1][0], a, B0R);                                                             \
+        /* q1: (A0, B1) */                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = read_frag(slot(t_, 3), brow, ks, lane);  \
+        bl.issue(t_ + 2, 0, slot(t_, 2));                                                                   \
+        GN_PHASE(acc[0][1], acc[1][1], a, B1R);                                                             \
+        /* q2: (A1, B1); B0 of the next K-tile must have landed one phase before q3 reads it */             \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = read_frag(slot(t_, 1), arow + f * 32, ks, lane); \
+        al.issue(t_ + 2, 0, slot(t_, 0));                                                                   \
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                    \
+        GN_PHASE(acc[2][1], acc[3][1], a, B1R);                                                             \
+        /* q3: (A1, B0); the counted wait that retires K-tile t+1 */                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = read_frag(slot(t_ + 1, 2), brow, ks, lane); \
+        bl.issue(t_ + 2, 1, slot(t_, 3));                                                                   \
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                    \
+        GN_PHASE(acc[2][0], acc[3][0], a, B0R);                                                             \
+    }
+
 #pragma unroll 1
-    for (int t = 0; t < ktiles; ++t) {
-        const char* sA0 = slot(t, 0);
-        const char* sA1 = slot(t, 1);
-        const char* sB0 = slot(t, 2);
-        const char* sB1 = slot(t, 3);
-        // ---- q0: quadrant (A0, B0) -> acc[0..1][0]
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) b0[ks] = read_frag(sB0, brow, ks, lane);
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[f][ks] = read_frag(sA0, arow + f * 32, ks, lane);
-        al.issue(t + 1, 1, slot(t + 1, 1));
-        GN_PHASE(acc[0][0], acc[1][0], a, b0);
-        // ---- q1: quadrant (A0, B1) -> acc[0..1][1]
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) b1[ks] = read_frag(sB1, brow, ks, lane);
-        al.issue(t + 2, 0, slot(t, 0));
-        GN_PHASE(acc[0][1], acc[1][1], a, b1);
-        // ---- q2: quadrant (A1, B1) -> acc[2..3][1]
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a[f][ks] = read_frag(sA1, arow + f * 32, ks, lane);
-        bl.issue(t + 2, 0, slot(t, 2));
-        GN_PHASE(acc[2][1], acc[3][1], a, b1);
-        // ---- q3: quadrant (A1, B0) -> acc[2..3][0]; the one counted wait of the K-tile
-        bl.issue(t + 2, 1, slot(t, 3));
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        GN_PHASE(acc[2][0], acc[3][0], a, b0);
+    for (int t = 0; t < ktiles; t += 2) {
+        GN_KTILE(t, bx, by);
+        if (t + 1 < ktiles) GN_KTILE(t + 1, by, bx);
     }
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // no DMA may land after the block has released its LDS
+    // drain: no DMA may land after the block has released its LDS, and the last MFMAs (16 passes) must have written back
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));                    // no DMA may land after the block has released its LDS
 
     // epilogue (conv forward: bias + ReLU; data gradient: raw)
     const int r = lane & 31, hh = lane >> 5;

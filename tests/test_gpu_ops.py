@@ -412,11 +412,13 @@ def test_to_bf16_padded_layout_exact():
     assert float(buf.float().abs().sum()) == float(want.abs().sum())       # guard bands stay zero
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])          # the 128 x 128 kernel and the 256 x 256 phased kernel (gemm_bf16_256.hip)
 @pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [
     (2, 7, 5, 64, 256, True, True), (3, 13, 13, 64, 256, True, True), (16, 11, 11, 256, 512, True, True),
-    (16, 11, 11, 512, 256, False, False), (2, 13, 13, 256, 64, False, False),
+    (16, 11, 11, 512, 256, False, False), (2, 13, 13, 256, 64, False, False), (9, 40, 36, 64, 320, True, True),
 ])
-def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu):
+def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu, tile, monkeypatch):
+    monkeypatch.setenv("GOALNET_BF16_TILE", tile)         # read by the entry point at call time; unset = chosen by size
     x = rnd(n, h, w, cin, seed=63)
     wt = rnd(cout, 3, 3, cin, seed=64, lo=-0.05, hi=0.05).to(torch.bfloat16)
     b = rnd(cout, seed=65) if bias else None
