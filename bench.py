@@ -253,7 +253,7 @@ def main():
                 except Exception:
                     traffic = None
             peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-            kname = ("gemm_bf16_256_kernel<ConvAPadLoader256<64>, KCLoader256<32>> (conv2 + conv3 forward, bf16 MFMA implicit GEMM, 256x256 phased tile, zero-padded bf16 activations)" if args.dtype == "bf16"
+            kname = ("gemm_bf16_256_kernel<ConvAPadLoader256<64>, KCLoader256<32>, 0> (conv2 + conv3 forward, bf16 MFMA implicit GEMM, 256x256 phased tile, zero-padded bf16 activations)" if args.dtype == "bf16"
                      else "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)")
             res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                                "frac": achieved / peak, "traffic": traffic,

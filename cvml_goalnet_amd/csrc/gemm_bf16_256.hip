@@ -139,7 +139,8 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
     }                                                                                                       \
     asm volatile("s_setprio 0\n\ts_barrier" ::: "memory");
 
-template <class AL, class BL>
+// ROLE only separates the symbols (0: convolution forward, 1: data gradient) so that profiles list them apart
+template <class AL, class BL, int ROLE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                               int tiles_m, int tiles_n, int m_fast, int ktiles) {
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
@@ -237,13 +238,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 namespace goalnet {
 
 // conv 3x3 forward / data gradient on zero-padded bf16 activations with the 256^2 phased tile; ep.mode RAW or BIAS_RELU
-int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
-                         int Cout, const EpiP& ep, hipStream_t st) {
+template <int ROLE>
+static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M,
+                                     const __hip_bfloat16* w, int Cout, const EpiP& ep, hipStream_t st) {
     typedef ConvAPadLoader256<64> AL;
     typedef KCLoader256<32> BL;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
@@ -251,10 +253,17 @@ int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, i
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     AL::P ap{x_pad, H, W, Cin, M};
     BL::P bp{w, (int64_t)9 * Cin, Cout};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
                        (int)tiles_m, (int)tiles_n, 0, 9 * Cin / BKH);
     GN_LAUNCH_CHECK(name);
     return 0;
+}
+
+// conv 3x3 forward (bias + ReLU epilogue) / data gradient (raw epilogue) on zero-padded bf16 activations, 256^2 phased tile
+int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
+                         int Cout, const EpiP& ep, hipStream_t st) {
+    return ep.mode == EPI_BIAS_RELU && ep.relu ? launch_conv_bf16_256_role<0>(name, x_pad, H, W, Cin, M, w, Cout, ep, st)
+                                               : launch_conv_bf16_256_role<1>(name, x_pad, H, W, Cin, M, w, Cout, ep, st);
 }
 
 }  // namespace goalnet
