@@ -583,9 +583,16 @@ static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {
     return (ktiles + kps - 1) / kps;
 }
 
+// large problems reduce on the 256 x 256 phased tile (gemm_bf16_256.hip); GOALNET_BF16_TILE=128 / 256 forces a choice
+static bool wgrad_use_256(int64_t Mp, int Cin, int Cout) {
+    const char* forced = getenv("GOALNET_BF16_TILE");
+    return forced ? forced[0] == '2' : (Cout % 256 == 0 && (9 * Cin) % 256 == 0 && Mp >= 262144);      // whole tiles only
+}
+
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     const int64_t Mp = (int64_t)N * (H + 2) * (W + 2);
-    return (size_t)wgrad_splits_h(Mp, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
+    const int a = wgrad_splits_h(Mp, Cin, Cout), b = wgrad_splits_256(Mp, Cin, Cout);       // enough for either kernel
+    return (size_t)(a > b ? a : b) * (size_t)Cout * 9 * Cin * sizeof(float);
 }
 
 /* dw[Cout][3][3][Cin] (fp32) = sum over the padded pixel grid of dy_pad[pm][co] * x_pad[pm + shift(tap)][ci] */
@@ -599,9 +606,17 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
     GN_REQUIRE(Mp < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_wgrad_bf16: too many pixels");
     GN_REQUIRE(ws_bytes >= goalnet_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout), GOALNET_E_WORKSPACE, "conv3x3_wgrad_bf16: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    const int64_t slab = (int64_t)Cout * 9 * Cin;
+    if (wgrad_use_256(Mp, Cin, Cout)) {
+        const int ns = wgrad_splits_256(Mp, Cin, Cout);
+        const int rc = launch_wgrad_bf16_256("conv3x3_wgrad_bf16(256)", (const __hip_bfloat16*)x_pad, (const __hip_bfloat16*)dy_pad, W + 2,
+                                             Cin, Cout, Mp, (float*)ws, ns, st);
+        if (rc) return rc;
+        EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+        return launch_splitk_reduce("conv3x3_wgrad_bf16(256).reduce", (const float*)ws, ns, slab, er, st);
+    }
     const int nsplit = wgrad_splits_h(Mp, Cin, Cout);
     const int ktiles = (int)((Mp + BKH - 1) / BKH);
-    const int64_t slab = (int64_t)Cout * 9 * Cin;
     MCLoaderH::P ap{(const __hip_bfloat16*)dy_pad, Cout, Cout, (int)Mp};
     ConvWgradBLoaderH::P bp{(const __hip_bfloat16*)x_pad, W + 2, Cin, Mp};
     EpiP ep{EPI_RAW, (float*)ws, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};

@@ -45,6 +45,7 @@ __device__ __forceinline__ int tile_row_of(int h, int lr) { return (lr / GROUP) 
 template <int GROUP>
 struct KCLoader256 {
     struct P { const __hip_bfloat16* x; int64_t ld; int rows; };
+    static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
     int wave;
@@ -74,6 +75,7 @@ struct KCLoader256 {
 template <int GROUP>
 struct ConvAPadLoader256 {
     struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; };
+    static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
     int Wp2, C, lgC, wave;
@@ -117,6 +119,96 @@ struct ConvAPadLoader256 {
     }
 };
 
+// ---- row-contiguous ("transposed") operands for the weight gradient: the reduction index (pixel) is the slow index in
+// memory. Half-tile image = [64 k-rows][128 columns] bf16 (256-B rows, 16-B chunks XOR-swizzled by 2 * (krow & 7) on the DMA
+// source address), read with ds_read_b64_tr_b16 exactly as in gemm_bf16.hip. Half h holds tile columns h*128 .. h*128+127;
+// fragment u (0..3) of a half is made of the 16-column units {u, u + 4}: columns 16u + (i & 15) + 64 (i >> 4), i = 0..31.
+constexpr int TROWB = 256;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ int tr_chunk(int krow, int chunk) { return chunk ^ (2 * (krow & 7)); }
+
+__device__ __forceinline__ bf16x8 read_frag_tr(const char* half, int u, int ks, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int chunk = 2 * (u + 4 * (g & 1)) + (p >> 1);
+    s16x4 v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int kr = 16 * ks + 8 * (g >> 1) + 4 * t + q;
+        const char* a = half + kr * TROWB + tr_chunk(kr, chunk) * 16 + (p & 1) * 8;
+        v[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
+    }
+    return bf16x8{v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+}
+
+// plain matrix X[kred][cols] (dy_pad [pixels][Cout]): re-based every K-tile; rows past kred / columns past `cols` read 0
+struct MCLoader256 {
+    struct P { const __hip_bfloat16* x; int64_t ld; int cols; int64_t kred; };
+    static constexpr bool TR = true;
+    const __hip_bfloat16* x;
+    int64_t ld, kred;
+    int wave;
+    unsigned voff[2][2];
+    __device__ MCLoader256(const P& p, int col0, int tid) {
+        x = p.x; ld = p.ld; kred = p.kred;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kr = (wave * 2 + i) * 4 + (lane >> 4);
+                const int col = col0 + h * 128 + tr_chunk(kr, lane & 15) * 8;
+                voff[h][i] = col < p.cols ? (unsigned)(((int64_t)kr * p.ld + col) * 2) : OOB;
+            }
+    }
+    __device__ __forceinline__ void issue(int kt, int h, char* l) const {
+        const int64_t kbase = (int64_t)kt * BKH;
+        const int64_t nk = kred - kbase < BKH ? kred - kbase : BKH;          // <= 0 past the end: empty range, zeros
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + kbase * ld, clamp_u32(nk * ld * 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], 0);
+    }
+};
+
+// B operand of the weight gradient on the zero-padded pixel grid: B(col = (tap, ci), k = pm) = x_pad[pm + shift(tap)][ci]
+// (constant pixel shift per tap; pad pixels contribute nothing because dy_pad is zero there). `x` = padded pixel 0 of a
+// buffer with W+3 zero guard pixels in front and behind.
+struct ConvWgradBLoader256 {
+    struct P { const __hip_bfloat16* x; int Wp2, C; int64_t Mp; };
+    static constexpr bool TR = true;
+    const __hip_bfloat16* x;
+    int64_t Mp;
+    int C, G, wave;
+    unsigned voff[2][2];
+    __device__ ConvWgradBLoader256(const P& p, int col0, int tid) {
+        x = p.x; C = p.C; G = p.Wp2 + 1; Mp = p.Mp;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kr = (wave * 2 + i) * 4 + (lane >> 4);
+                const int col = col0 + h * 128 + tr_chunk(kr, lane & 15) * 8;
+                if (col < 9 * p.C) {
+                    const int tap = col / p.C, ci = col - tap * p.C;
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    voff[h][i] = (unsigned)(((kr + kh * p.Wp2 + kw) * p.C + ci) * 2);       // relative to pixel (kbase - G)
+                } else {
+                    voff[h][i] = OOB;
+                }
+            }
+    }
+    __device__ __forceinline__ void issue(int kt, int h, char* l) const {
+        const int64_t kbase = (int64_t)kt * BKH;
+        // K-tiles past the pixel grid (staged only to keep the DMA counts uniform) get an empty range: zeros, no access
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (kbase - G) * C, kbase < Mp ? (uint32_t)((BKH + 2 * G) * C * 2) : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], 0);
+    }
+};
+
 __device__ __forceinline__ bf16x8 read_frag(const char* half, int row0, int ks, int lane) {
     return *reinterpret_cast<const bf16x8*>(half + kc_boff(row0 + (lane & 31), 2 * ks + (lane >> 5)));
 }
@@ -142,7 +234,10 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
 // ROLE only separates the symbols (0: convolution forward, 1: data gradient) so that profiles list them apart
 template <class AL, class BL, int ROLE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
-                                                              int tiles_m, int tiles_n, int m_fast, int ktiles) {
+                                                              int tiles_m, int tiles_n, int m_fast, int ktiles_total,
+                                                              int ktiles_per_split) {
+    static_assert(AL::TR == BL::TR, "both operands K-contiguous or both row-contiguous");
+    constexpr bool TRF = AL::TR;
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
     int tm, tn;
@@ -151,6 +246,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     const BL bl(bp, tn * T, tid);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    const int kt0 = blockIdx.y * ktiles_per_split;                      // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
+    const int ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -163,8 +260,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     auto slot = [&](int t, int s) -> char* { return lds + ((t & 1) * 4 + s) * HALF_BYTES; };     // s: 0 A0, 1 A1, 2 B0, 3 B1
 
     // prologue: K-tile 0 complete, K-tile 1 without its A1 (phase (0,q0) stages that)
-    al.issue(0, 0, slot(0, 0)); bl.issue(0, 0, slot(0, 2)); bl.issue(0, 1, slot(0, 3)); al.issue(0, 1, slot(0, 1));
-    bl.issue(1, 0, slot(1, 2)); al.issue(1, 0, slot(1, 0)); bl.issue(1, 1, slot(1, 3));
+    al.issue(kt0 + 0, 0, slot(0, 0)); bl.issue(kt0 + 0, 0, slot(0, 2)); bl.issue(kt0 + 0, 1, slot(0, 3)); al.issue(kt0 + 0, 1, slot(0, 1));
+    bl.issue(kt0 + 1, 0, slot(1, 2)); al.issue(kt0 + 1, 0, slot(1, 0)); bl.issue(kt0 + 1, 1, slot(1, 3));
     asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     if (wr == 1) asm volatile("s_barrier" ::: "memory");                 // stagger the two wave rows by one barrier
 
@@ -172,31 +269,36 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // fragments of the NEXT K-tile are read in phase q3 into the registers B1 has just left, so every phase issues at most
     // 8 ds_read_b128 per wave (8 | 4 | 8 | 4) and the LDS time of a phase stays within one MFMA section.
     bf16x8 a[2][4], bx[4], by[4];
-    const int arow = wr * 64, brow = wc * 32;
+    auto rdA = [&](const char* half, int f, int ks) -> bf16x8 {
+        return TRF ? read_frag_tr(half, 2 * wr + f, ks, lane) : read_frag(half, wr * 64 + f * 32, ks, lane);
+    };
+    auto rdB = [&](const char* half, int ks) -> bf16x8 {
+        return TRF ? read_frag_tr(half, wc, ks, lane) : read_frag(half, wc * 32, ks, lane);
+    };
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bx[ks] = read_frag(slot(0, 2), brow, ks, lane);
+    for (int ks = 0; ks < 4; ++ks) bx[ks] = rdB(slot(0, 2), ks);
 
 #define GN_KTILE(TT, B0R, B1R)                                                                              \
     {                                                                                                       \
         const int t_ = (TT);                                                                                \
         /* q0: (A0, B0) */                                                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = read_frag(slot(t_, 0), arow + f * 32, ks, lane); \
-        al.issue(t_ + 1, 1, slot(t_ + 1, 1));                                                               \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = rdA(slot(t_, 0), f, ks); \
+        al.issue(kt0 + t_ + 1, 1, slot(t_ + 1, 1));                                                               \
         GN_PHASE(acc[0][0], acc[1][0], a, B0R);                                                             \
         /* q1: (A0, B1) */                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = read_frag(slot(t_, 3), brow, ks, lane);  \
-        bl.issue(t_ + 2, 0, slot(t_, 2));                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = rdB(slot(t_, 3), ks);  \
+        bl.issue(kt0 + t_ + 2, 0, slot(t_, 2));                                                                   \
         GN_PHASE(acc[0][1], acc[1][1], a, B1R);                                                             \
         /* q2: (A1, B1); B0 of the next K-tile must have landed one phase before q3 reads it */             \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = read_frag(slot(t_, 1), arow + f * 32, ks, lane); \
-        al.issue(t_ + 2, 0, slot(t_, 0));                                                                   \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = rdA(slot(t_, 1), f, ks); \
+        al.issue(kt0 + t_ + 2, 0, slot(t_, 0));                                                                   \
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                    \
         GN_PHASE(acc[2][1], acc[3][1], a, B1R);                                                             \
         /* q3: (A1, B0); the counted wait that retires K-tile t+1 */                                        \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = read_frag(slot(t_ + 1, 2), brow, ks, lane); \
-        bl.issue(t_ + 2, 1, slot(t_, 3));                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = rdB(slot(t_ + 1, 2), ks); \
+        bl.issue(kt0 + t_ + 2, 1, slot(t_, 3));                                                                   \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                    \
         GN_PHASE(acc[2][0], acc[3][0], a, B0R);                                                             \
     }
@@ -214,21 +316,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));                    // no DMA may land after the block has released its LDS
 
-    // epilogue (conv forward: bias + ReLU; data gradient: raw)
+    // epilogue (conv forward: bias + ReLU; data gradient: raw; weight gradient: raw split-K slab)
     const int r = lane & 31, hh = lane >> 5;
-    const bool brelu = ep.mode == EPI_BIAS_RELU;
+    const bool brelu = ep.mode == EPI_BIAS_RELU && ep.slab_stride == 0;
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)blockIdx.y * ep.slab_stride : 0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int col = tn * T + wc * 64 + ni * 32 + r;
+            const int col = tn * T + (TRF ? ni * 128 + 16 * wc + (r & 15) + 64 * (r >> 4) : wc * 64 + ni * 32 + r);
             const bool colok = col < ep.cols;
             const float bv = (brelu && ep.bias && colok) ? ep.bias[col] : 0.f;
             const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = (int64_t)tm * T + wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (colok && row < ep.rows) ep.out[row * ep.ld + col] = fmaxf(acc[mi][ni][e] + bv, lo);
+                const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int64_t row = (int64_t)tm * T + (TRF ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (i & 15) + 64 * (i >> 4)
+                                                           : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + i);
+                if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[mi][ni][e] + bv, lo);
             }
         }
 }
@@ -254,7 +359,7 @@ static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_p
     AL::P ap{x_pad, H, W, Cin, M};
     BL::P bp{w, (int64_t)9 * Cin, Cout};
     hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
-                       (int)tiles_m, (int)tiles_n, 0, 9 * Cin / BKH);
+                       (int)tiles_m, (int)tiles_n, 0, 9 * Cin / BKH, 9 * Cin / BKH);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
@@ -264,6 +369,44 @@ int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, i
                          int Cout, const EpiP& ep, hipStream_t st) {
     return ep.mode == EPI_BIAS_RELU && ep.relu ? launch_conv_bf16_256_role<0>(name, x_pad, H, W, Cin, M, w, Cout, ep, st)
                                                : launch_conv_bf16_256_role<1>(name, x_pad, H, W, Cin, M, w, Cout, ep, st);
+}
+
+// split count of the weight gradient on 256 x 256 tiles: ~2048 blocks, a whole number of 256-CU rounds where possible
+int wgrad_splits_256(int64_t Mp, int Cin, int Cout) {
+    const int64_t tiles = (int64_t)((Cout + T - 1) / T) * ((9 * Cin + T - 1) / T);
+    const int ktiles = (int)((Mp + BKH - 1) / BKH);
+    int64_t s = (2048 + tiles - 1) / tiles;
+    const int64_t smax = ktiles / 64 > 1 ? ktiles / 64 : 1;             // >= 64 K-tiles per split: the 7-half-tile prologue stays < 3 %
+    if (s > smax) s = smax;
+    for (int64_t c = s; c < s + 32 && c <= smax; ++c)
+        if ((tiles * c) % 256 == 0) { s = c; break; }
+    if (s > 1024) s = 1024;
+    const int kps = (int)((ktiles + s - 1) / s);
+    return (ktiles + kps - 1) / kps;
+}
+
+// conv 3x3 weight gradient on the zero-padded pixel grid: slabs[split][Cout][9*Cin] (fp32), reduced by the caller
+int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
+                          int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
+    typedef MCLoader256 AL;
+    typedef ConvWgradBLoader256 BL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int64_t tiles_m = (Cout + T - 1) / T, tiles_n = (9 * Cin + T - 1) / T;
+    const int ktiles = (int)((Mp + BKH - 1) / BKH);
+    GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
+    const int kps = (ktiles + nsplit - 1) / nsplit;
+    AL::P ap{dy_pad, Cout, Cout, Mp};
+    BL::P bp{x_pad, Wp2, Cin, Mp};
+    EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 2>), dim3((unsigned)(tiles_m * tiles_n), (unsigned)nsplit), dim3(512), LDS_BYTES, st,
+                       ap, bp, ep, (int)tiles_m, (int)tiles_n, 1, ktiles, kps);
+    GN_LAUNCH_CHECK(name);
+    return 0;
 }
 
 }  // namespace goalnet

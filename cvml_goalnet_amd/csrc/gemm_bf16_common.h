@@ -32,4 +32,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_dst, u
 int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
                          int Cout, const EpiP& ep, hipStream_t st);
 
+int wgrad_splits_256(int64_t Mp, int Cin, int Cout);
+int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
+                          int64_t Mp, float* slabs, int nsplit, hipStream_t st);
+
 }  // namespace goalnet

@@ -431,8 +431,11 @@ def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu, tile, mon
     close(f"conv3x3_fwd_bf16p[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 7, 5, 64, 256), (3, 13, 13, 64, 256), (16, 11, 11, 256, 512), (5, 9, 6, 64, 128)])
-def test_conv3x3_wgrad_bf16(n, h, w, cin, cout):
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 7, 5, 64, 256), (3, 13, 13, 64, 256), (16, 11, 11, 256, 512), (5, 9, 6, 64, 128),
+                                            (40, 30, 26, 64, 320)])
+def test_conv3x3_wgrad_bf16(n, h, w, cin, cout, tile, monkeypatch):
+    monkeypatch.setenv("GOALNET_BF16_TILE", tile)
     x = rnd(n, h, w, cin, seed=66)
     dy = rnd(n, h, w, cout, seed=67)
     _, xp = _padded(x)
