@@ -148,8 +148,8 @@ def native40_loop(dev, frames=300, videos=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=64, help="clips of 16 frames per GPU per step")
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -342,6 +342,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
     store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, split, wm, wn, lane);
 }
 
+// A short reduction with a huge output (linear5 dW: 16 K-tiles, 5 GB written): the time goes into per-block latency
+// (prologue wait, a DMA round trip per K-tile, the tile store), not into MFMA or LDS. One LDS stage (32 KB) instead of two
+// lets 4 blocks share a CU, which hides those latencies behind each other.
+template <class AL, class BL>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_1stage_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
+                                                                  int tiles_m, int tiles_n, int m_fast, int ktiles) {
+    __shared__ __attribute__((aligned(16))) char lds[2][OP_BYTES];
+    const int tid = threadIdx.x;
+    int tm, tn;
+    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
+    const AL al(ap, tm * BM, tid);
+    const BL bl(bp, tn * BN, tid);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        al.issue(kt, lds[0]);
+        bl.issue(kt, lds[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute_tile_h<AL::TR, BL::TR>(lds[0], lds[1], acc, wm, wn, lane);
+        __syncthreads();                                        // everyone has read the tile before it is overwritten
+    }
+    store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, 0, wm, wn, lane);
+}
+
+template <class AL, class BL>
+int launch_gemm_h_1stage(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
+                         int64_t M, int64_t N, int ktiles, int m_fast, hipStream_t st) {
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
+    hipLaunchKernelGGL((gemm_bf16_1stage_kernel<AL, BL>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, ap, bp, ep,
+                       (int)tiles_m, (int)tiles_n, m_fast, ktiles);
+    GN_LAUNCH_CHECK(name);
+    return 0;
+}
+
 template <class AL, class BL>
 int launch_gemm_h(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
                   int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, hipStream_t st) {
@@ -649,7 +692,9 @@ int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_
     MCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, J, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)x_bf16, ldx, (int)K, M};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
-    return launch_gemm_h<MCLoaderH, MCLoaderH>("linear_bwd_dw_bf16", ap, bp, ep, J, K, (M + BKH - 1) / BKH, 1, 1, (hipStream_t)stream);
+    // measured at M = 1024, K = 2.5 M: 3.8 ms with one stage and 4 blocks per CU vs 4.7 ms with two stages and 2 (the data
+    // gradient, whose W tiles are 256-B pieces 5 MB apart, is the other way round: 10.2 vs 6.6 ms, and keeps two stages)
+    return launch_gemm_h_1stage<MCLoaderH, MCLoaderH>("linear_bwd_dw_bf16", ap, bp, ep, J, K, (M + BKH - 1) / BKH, 1, (hipStream_t)stream);
 }
 
 }  // extern "C"

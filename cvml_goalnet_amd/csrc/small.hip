@@ -76,6 +76,65 @@ __global__ __launch_bounds__(256) void conv1d_dx_kernel(const float* __restrict_
     }
 }
 
+// ---- the same two gradients for many frames (N >= 64: the 1024-frame batches of bench.py) -----------------------------
+// dX: one thread per output, channels fastest so that a wave reads the weights w[co][ci..ci+63][k] as one 768-B run
+__global__ __launch_bounds__(256) void conv1d_dx_big_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int N, int Cin, int L, int Cout, int Lo,
+                                                           int stride, int pad) {
+    const int64_t total = (int64_t)N * L * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const int l = (int)((i / Cin) % L);
+        const int64_t n = i / ((int64_t)Cin * L);
+        const float* dzs = dz + n * Cout * Lo;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = l + pad - k;
+            if (t < 0 || t % stride != 0) continue;
+            const int lo = t / stride;
+            if (lo >= Lo) continue;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(dzs[co * Lo + lo], w[((int64_t)co * Cin + ci) * 3 + k], acc);
+        }
+        dx[(n * Cin + ci) * L + l] = acc;
+    }
+}
+
+// dW: block = 4 x 4 (co, ci) pairs x 16 frame lanes; every lane walks its frames (fp32 per frame, fp64 across frames), the 16
+// lane totals of a pair are added in a fixed order. The block re-uses each dz / x row 4 times from L1.
+__global__ __launch_bounds__(256) void conv1d_dw_big_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                           float* __restrict__ dw, int N, int Cin, int L, int Cout, int Lo,
+                                                           int stride, int pad) {
+    __shared__ double red[16][16][3];
+    const int pair = threadIdx.x >> 4, lanef = threadIdx.x & 15;
+    const int cig = (Cin + 3) / 4;
+    const int co = (blockIdx.x / cig) * 4 + (pair >> 2), ci = (blockIdx.x % cig) * 4 + (pair & 3);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (co < Cout && ci < Cin) {
+        for (int n = lanef; n < N; n += 16) {
+            const float* xs = x + ((int64_t)n * Cin + ci) * L;
+            const float* ds = dz + ((int64_t)n * Cout + co) * Lo;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int lo = 0; lo < Lo; ++lo) {
+                const float d = ds[lo];
+                const int l0 = stride * lo - pad;
+                if ((unsigned)(l0) < (unsigned)L) s0 = fmaf(d, xs[l0], s0);
+                if ((unsigned)(l0 + 1) < (unsigned)L) s1 = fmaf(d, xs[l0 + 1], s1);
+                if ((unsigned)(l0 + 2) < (unsigned)L) s2 = fmaf(d, xs[l0 + 2], s2);
+            }
+            a0 += s0; a1 += s1; a2 += s2;
+        }
+    }
+    red[pair][lanef][0] = a0; red[pair][lanef][1] = a1; red[pair][lanef][2] = a2;
+    __syncthreads();
+    if (lanef < 3 && co < Cout && ci < Cin) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[pair][j][lanef];
+        dw[((int64_t)co * Cin + ci) * 3 + lanef] = (float)t;
+    }
+}
+
 // dw[co][ci][k] = sum_{n,lo} dz[n][co][lo] * x[n][ci][stride*lo - pad + k]; one block per (co, ci), the 256
 // threads split the frames, fp64 block reduction (deterministic).
 __global__ __launch_bounds__(256) void conv1d_dw_kernel(const float* __restrict__ x, const float* __restrict__ dz,
@@ -312,11 +371,18 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
     GN_REQUIRE(N > 0 && Cin > 0 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE, "conv1d_bwd: bad dims");
     const int Lo = (L + 2 * pad - 3) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
+    const bool many = N >= 64;          // few frames (the reference's sub-batches): lanes split the channels; many: lanes split the frames
     if (dx) {
-        hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L * 16)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
+        if (many)
+            hipLaunchKernelGGL(conv1d_dx_big_kernel, dim3(grid1d((int64_t)N * Cin * L)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
+        else
+            hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L * 16)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
         GN_LAUNCH_CHECK("conv1d_bwd.dx");
     }
-    hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
+    if (many)
+        hipLaunchKernelGGL(conv1d_dw_big_kernel, dim3(((Cout + 3) / 4) * ((Cin + 3) / 4)), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
+    else
+        hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
     GN_LAUNCH_CHECK("conv1d_bwd.dw");
     hipLaunchKernelGGL(conv1d_db_kernel, dim3(Cout), dim3(256), 0, st, dz, db, N, Cout, Lo);
     GN_LAUNCH_CHECK("conv1d_bwd.db");
