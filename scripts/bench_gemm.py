@@ -72,6 +72,36 @@ def lin5_case(hw3):
     print(f"linear5 dW    : {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
 
 print(f"N = {n} frames; variant = {os.environ.get('GOALNET_GEMM_VARIANT', '0')}")
-conv_case("conv3 72x72 256->512", 72, 72, 256, 512)
-conv_case("conv2 74x74  64->256", 74, 74, 64, 256)
-lin5_case(70 * 70)
+which = sys.argv[2] if len(sys.argv) > 2 else "gemm"
+if which == "gemm":
+    conv_case("conv3 72x72 256->512", 72, 72, 256, 512)
+    conv_case("conv2 74x74  64->256", 74, 74, 64, 256)
+if which in ("gemm", "lin"):
+    lin5_case(70 * 70)
+
+
+def pool_case(name, hc, wc, c):
+    """HBM-bound block kernels: max-pool + BN statistics forward, fused BN/pool/ReLU backward"""
+    y = torch.relu(torch.randn(n, hc, wc, c, device=dev))
+    hp, wp = hc - 2, wc - 2
+    p = torch.empty(n, hp, wp, c, device=dev); idx = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=dev)
+    parts = ops.stat_parts(8 * n)
+    partials = torch.empty(parts * 2 * c, dtype=torch.float64, device=dev)
+    t, ta = timeit(lambda: ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c))
+    gb = (y.numel() * 4 + p.numel() * 5) / 1e9
+    print(f"{name} pool fwd : {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    dz = torch.randn(n, hp, wp, c, device=dev); coef3 = torch.randn(3 * c, device=dev)
+    dparts = torch.empty(parts * c, dtype=torch.float64, device=dev)
+    dy = torch.empty(n, hc, wc, c, device=dev)
+    t, ta = timeit(lambda: ops.bnpool_bwd(dz, p, idx, y, coef3, dy, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 8) / 1e9
+    print(f"{name} bnpool bwd (fp32 dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    bd, dyp = ops.padded_bf16_alloc(n, hc, wc, c, dev)
+    t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dz, p, idx, y, coef3, None, dyp, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 6) / 1e9
+    print(f"{name} bnpool bwd (bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "pool":
+    pool_case("block3 72x72x512", 72, 72, 512)
+    pool_case("block2 74x74x256", 74, 74, 256)

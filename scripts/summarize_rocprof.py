@@ -35,7 +35,7 @@ if f:
     with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as o:
         o.write(f"# rocprofv3 --kernel-trace --stats — bench.py ({tag})\n\n")
         o.write("Command (on the MI355X box, scripts/profile_bench.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- "
-                "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --dtype <see bench line>` (3 train steps in the trace: 1 warm-up + 2 timed).\n\n")
+                "python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-native40 --dtype <see bench line>` (4 train steps in the trace: 2 warm-up + 2 timed).\n\n")
         if bench:
             o.write(f"bench line of the same run: value = {bench['value']:.2f} clips/s, {bench['ms_per_step']:.1f} ms/step; "
                     f"roofline: {json.dumps(bench.get('roofline'))}\n\n")
@@ -59,7 +59,7 @@ if agg:
     with open(os.path.join(out, f"{tag}_traffic.md"), "w") as o:
         o.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) — bench.py ({tag})\n\n")
         o.write("Counter unit: KiB. HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, "
-                "MI355X_MICROARCH.md §HBM). Average over the launches of each kernel in 3 train steps.\n\n")
+                "MI355X_MICROARCH.md §HBM). Average over the launches of each kernel in 4 train steps.\n\n")
         o.write("| kernel | launches | FETCH_SIZE avg (KiB) | WRITE_SIZE avg (KiB) | HBM GB / launch |\n|---|---:|---:|---:|---:|\n")
         items = []
         for k, v in agg.items():
