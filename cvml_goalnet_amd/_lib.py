@@ -80,6 +80,7 @@ PROTOTYPES = {
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
+    "goalnet_frames_preprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "goalnet_knapsack_ws_bytes": (c_size_t, [c_int, c_int]),
     "goalnet_knapsack": (c_int, [P, P, c_int, c_int, P, P, c_size_t, P]),
     "goalnet_fscore": (c_int, [P, P, c_int, c_int, P, P, P]),

@@ -241,6 +241,13 @@ int goalnet_postprocess(const float* pred, int n_sampled, int skip_frames, int f
                         int32_t* selected, int64_t* clip_values, int32_t* clip_lengths, double* fscore, int32_t* status,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---- before the hot path: frame pre-processing of the loader.  utils.py:274-292 (decode excluded) -----------------
+ * frames_hwc: device uint8 [N][H0][W0][3] (BGR as cv2 decodes); out_nchw: float32 [N][3][H][W] = per-frame min-max
+ * normalisation (float64, + 1e-7) -> float32 -> bilinear resize (cv2.resize INTER_LINEAR semantics) -> channel-first.
+ * minmax: scratch int32 [N][2]. PARITY UNPINNED (OpenCV absent from the build image). */
+int goalnet_frames_preprocess(const uint8_t* frames_hwc, int N, int H0, int W0, float* out_nchw, int H, int W,
+                              int32_t* minmax, void* stream);
+
 /* up to GOALNET_ROWCOPY_MAX gathers (gather != 0: dst[0:nrows] = src[c : c + nrows]) and scatters
  * (gather == 0: dst[c : c + nrows] = src[0:nrows]) in one launch; c = *cursor + cursor_bias */
 #define GOALNET_ROWCOPY_MAX 4
