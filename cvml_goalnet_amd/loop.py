@@ -128,6 +128,23 @@ class VideoTrainer:
         self._host_bookkeeping_after_replay()
         self.replays += 1
 
+    # ---- validation pass ---------------------------------------------------------------------------------------------
+    def eval_video(self, val_audios, val_frames, val_labels):
+        """main.py:218-226 for one video: the whole video in ONE forward under no_grad (BatchNorm in train mode, running
+        statistics updated, dropout live — the reference never calls .eval()), then nn.MSELoss with its (n,1) x (n,)
+        broadcast. Returns (loss (1,), predictions (N,)) as GPU tensors; nothing has been synchronised."""
+        m = self.model
+        m._require_device()
+        aud, vis, _ = m._to_device_inputs(val_audios, val_frames)
+        lab = torch.as_tensor(val_labels).detach().to(device=m._device, dtype=F32).reshape(-1).contiguous()
+        if lab.numel() != vis.shape[0]:
+            raise RuntimeError(f"{lab.numel()} labels for {vis.shape[0]} frames")
+        with torch.no_grad():
+            out, _ = m.forward_device(aud, vis, save=False)
+        loss = torch.empty(1, dtype=F32, device=m._device)
+        ops.mse_bcast(out, lab, loss, None)
+        return loss, out
+
     # ---- the loop ------------------------------------------------------------------------------------------------
     def train_video(self, batch_audios, batch_frames, batch_labels):
         """One video (main.py:169-203). batch_frames (N,3,H,W), batch_audios (N,30,B) or a list of None,

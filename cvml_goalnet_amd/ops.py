@@ -106,6 +106,12 @@ def _rows(partials, width):
     return n
 
 
+def idx_to_nhwc(idx, N, Hp, Wp, C):
+    """argmax bytes as the kernels store them ([N][C/S][Hp][Wp][S], S = 32 or C; include/goalnet_hip.h) -> (N, Hp, Wp, C)"""
+    S = 32 if C % 32 == 0 else C
+    return idx.reshape(N, C // S, Hp, Wp, S).permute(0, 2, 3, 1, 4).reshape(N, Hp, Wp, C)
+
+
 def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     _chk(y, p, idx, partials)
     assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C

@@ -69,7 +69,8 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
                         void* ws, size_t ws_bytes, int N, int H, int W, void* stream);
 
 /* ---- MaxPool2d(3,1,0) + train-mode BatchNorm statistics.  utils.py:153-154 (and 158-159, 163-164) */
-/* p = maxpool3x3s1(y); idx = argmax position 0..8 (first max in kh,kw scan order, as ATen);
+/* p = maxpool3x3s1(y); idx = argmax position 0..8 (first max in kh,kw scan order, as ATen), stored slice-major:
+ * [N][C / S][Hc-2][Wc-2][S] bytes with S = 32 (S = C when C % 32 != 0) so that stores are whole cache lines;
  * partials[nparts][2][C] (double) = per-block sum and sum of squares of p. */
 int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials, int nparts,
                              int N, int Hc, int Wc, int C, void* stream);

@@ -90,6 +90,8 @@ def pool_case(name, hc, wc, c):
     t, ta = timeit(lambda: ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c))
     gb = (y.numel() * 4 + p.numel() * 5) / 1e9
     print(f"{name} pool fwd : {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    t, ta = timeit(lambda: ops.pool_bnstats_fwd(y, p, None, partials, n, hc, wc, c))
+    print(f"{name} pool fwd without the argmax store: {t:8.3f} ms  {(y.numel() * 4 + p.numel() * 4) / 1e9 / t * 1e3:7.0f} GB/s")
     dz = torch.randn(n, hp, wp, c, device=dev); coef3 = torch.randn(3 * c, device=dev)
     dparts = torch.empty(parts * c, dtype=torch.float64, device=dev)
     dy = torch.empty(n, hc, wc, c, device=dev)

@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from _golden import GOLDEN_CASES_BIG, GOLDEN_CASES_SMALL, Golden  # noqa: E402
-from cvml_goalnet_amd import AVM, synth  # noqa: E402
+from cvml_goalnet_amd import AVM, ops, synth  # noqa: E402
 from oracle import avm_ref  # noqa: E402
 
 DEV = "cuda:0"
@@ -56,7 +56,11 @@ def _weight_of(name):
 
 def hip_taps(ctx):
     """argmax positions the device used in its three max-pools, as (N,C,Hp,Wp) uint8 CPU tensors"""
-    return {i: ctx[f"idx{i}"].cpu().permute(0, 3, 1, 2).contiguous() for i in (1, 2, 3)}
+    out = {}
+    for i in (1, 2, 3):
+        n, hp, wp, c = ctx[f"idx{i}"].shape                              # stored slice-major by the kernels (ops.idx_to_nhwc)
+        out[i] = ops.idx_to_nhwc(ctx[f"idx{i}"], n, hp, wp, c).cpu().permute(0, 3, 1, 2).contiguous()
+    return out
 
 
 NEAR_TIE = 1e-5   # a top-2 gap below 1e-5 x max|activation| of the layer is within the convolution's fp32 rounding

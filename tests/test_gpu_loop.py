@@ -162,3 +162,22 @@ def test_trainer_input_validation_and_table_growth():
     torch.cuda.synchronize()
     assert l2.shape == (13,) and p2.shape == (130,)
     assert torch.isfinite(l2).all() and ((p2 > 1) & (p2 < 5)).all()
+
+
+def test_eval_video_matches_the_oracle_forward_and_broadcast_loss():
+    """main.py:218-226: whole video, no_grad, train-mode BatchNorm (buffers move), (n,1) x (n,) MSE"""
+    n, h = 23, 40
+    model = load_model(h, True)
+    model.dropout_mode = "off"
+    aud, vis, lab = _video(n, h, True, 5)
+    tr = VideoTrainer(model)
+    loss, pred = tr.eval_video(aud, vis, lab)
+    p = {k: torch.from_numpy(v) for k, v in synth.make_params(h, h, 30, True).items()}
+    b = avm_ref.init_buffers()
+    with torch.no_grad():
+        want = avm_ref.forward(p, b, aud, vis, None, True, {})
+    assert (pred.cpu() - want.view(-1)).abs().max().item() < 2e-5
+    assert abs(loss.item() - avm_ref.mse_bcast(want, lab).item()) < 2e-5
+    sd = model.state_dict()
+    for k, v in b.items():                                               # running statistics were updated, as in the reference
+        assert torch.allclose(sd[k].double(), v.double(), rtol=1e-5, atol=1e-6), k

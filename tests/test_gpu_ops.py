@@ -175,7 +175,7 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c, parts):
     ph = torch.arange(hp).view(1, 1, hp, 1)
     pw = torch.arange(wp).view(1, 1, 1, wp)
     tap = ((ih - ph) * 3 + (iw - pw)).to(torch.uint8)
-    assert torch.equal(idx.cpu(), nhwc(tap)), "argmax positions differ from ATen's"
+    assert torch.equal(ops.idx_to_nhwc(idx, n, hp, wp, c).cpu(), nhwc(tap)), "argmax positions differ from ATen's"
     mean = pd.mean(dim=(0, 2, 3))
     var = pd.var(dim=(0, 2, 3), unbiased=False)
     close("bn.mean", st[0], mean, rtol=1e-6)
