@@ -40,8 +40,8 @@ PROTOTYPES = {
     "goalnet_bn_finalize": (c_int, [P, c_int, P, P, P, P, c_float, c_float, c_int64, c_int, P, P, P, P, P]),
     "goalnet_bn_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P]),
     "goalnet_bn_bwd_finalize": (c_int, [P, c_int, P, P, P, c_int64, c_int, P, P, P, P]),
-    "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

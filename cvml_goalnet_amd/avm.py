@@ -404,6 +404,7 @@ class AVM(nn.Module):
         y1 = torch.empty(n, h1, w1, 64, dtype=F32, device=dev)
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
+        del y1          # the conv output is only an input of the pool: backward reads the ReLU mask off p (csrc/pool_bn.hip)
         y2 = torch.empty(n, hp1, wp1, 256, dtype=F32, device=dev)
         bf = self.precision == "bf16"
         BF16 = torch.bfloat16
@@ -416,6 +417,7 @@ class AVM(nn.Module):
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
+        del y2
         y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
         if bf:
             xh2 = ops.to_bf16_padded(p2, st2[2], st2[3], self._padbuf("x2" if save else "x2e", n, hp2, wp2, 256), n, hp2, wp2, 256)
@@ -426,6 +428,7 @@ class AVM(nn.Module):
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
         p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save)
+        del y3
 
         fw = 640 if self.audio_included else 512
         voff = fw - 512
@@ -473,7 +476,7 @@ class AVM(nn.Module):
         out = torch.empty(n, dtype=F32, device=dev)
         ops.head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
         if save:
-            ctx.update(y1=y1, p1=p1, idx1=idx1, st1=st1, y2=y2, p2=p2, idx2=idx2, st2=st2, y3=y3, p3=p3, idx3=idx3, st3=st3,
+            ctx.update(p1=p1, idx1=idx1, st1=st1, p2=p2, idx2=idx2, st2=st2, p3=p3, idx3=idx3, st3=st3,
                        a1=a1, a2=a2, hs=hs, ms=ms, logit=logit, out=out, l1=l1, l2=l2)
         self.last_logit = logit
         return out, ctx
@@ -483,7 +486,7 @@ class AVM(nn.Module):
         Returns dy (N,hc,wc,c) = grad wrt the conv's pre-ReLU output; writes dgamma, dbeta, dbias into the grad arena."""
         dev = self._device
         G = self._gflat
-        p, idx, y, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"y{i}"], ctx[f"st{i}"]
+        p, idx, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"st{i}"]
         npix = n * (hc - 2) * (wc - 2)
         partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
         ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, npix, c)
@@ -494,10 +497,10 @@ class AVM(nn.Module):
         if self.precision == "bf16" and i > 1:
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
             dy = self._padbuf(f"dy{i}", n, hc, wc, c)
-            ops.bnpool_bwd_bf16p(dbn, p, idx, y, coef3, None, dy, dparts, n, hc, wc, c)
+            ops.bnpool_bwd_bf16p(dbn, p, idx, coef3, None, dy, dparts, n, hc, wc, c)
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
-            ops.bnpool_bwd(dbn, p, idx, y, coef3, dy, dparts, n, hc, wc, c)
+            ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
         ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
         return dy
 

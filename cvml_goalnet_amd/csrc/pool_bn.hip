@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 // ---- backward phase 3: dy[n,h,w,c] = relu'(y) * sum over the (<= 9) pooling windows that contain (h,w) and
 // whose argmax is (h,w) of dp[window], dp = a*dz + b*p + cc. A gather (no atomics, deterministic).
 __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ p,
-                                                        const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                                        const uint8_t* __restrict__ idx,
                                                         const float* __restrict__ coef3, float* __restrict__ dy,
                                                         double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
     __shared__ double smem[256 * 4];
@@ -234,16 +234,12 @@ __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict
                 const float4 d = *reinterpret_cast<const float4*>(dz + q);
                 const float4 x = *reinterpret_cast<const float4*>(p + q);
                 const unsigned k = dh * 3 + dw;
-                acc.x += (ok && (ii & 0xffu) == k) ? fmaf(ca.x, d.x, fmaf(cb.x, x.x, cc.x)) : 0.f;
-                acc.y += (ok && ((ii >> 8) & 0xffu) == k) ? fmaf(ca.y, d.y, fmaf(cb.y, x.y, cc.y)) : 0.f;
-                acc.z += (ok && ((ii >> 16) & 0xffu) == k) ? fmaf(ca.z, d.z, fmaf(cb.z, x.z, cc.z)) : 0.f;
-                acc.w += (ok && (ii >> 24) == k) ? fmaf(ca.w, d.w, fmaf(cb.w, x.w, cc.w)) : 0.f;
+                // ReLU mask from p: a window whose argmax is this pixel has p == y here, so (y > 0) == (p > 0) for every term
+                acc.x += (ok && (ii & 0xffu) == k && x.x > 0.f) ? fmaf(ca.x, d.x, fmaf(cb.x, x.x, cc.x)) : 0.f;
+                acc.y += (ok && ((ii >> 8) & 0xffu) == k && x.y > 0.f) ? fmaf(ca.y, d.y, fmaf(cb.y, x.y, cc.y)) : 0.f;
+                acc.z += (ok && ((ii >> 16) & 0xffu) == k && x.z > 0.f) ? fmaf(ca.z, d.z, fmaf(cb.z, x.z, cc.z)) : 0.f;
+                acc.w += (ok && (ii >> 24) == k && x.w > 0.f) ? fmaf(ca.w, d.w, fmaf(cb.w, x.w, cc.w)) : 0.f;
             }
-        const float4 yy = *reinterpret_cast<const float4*>(y + pix * C + g * 4);
-        acc.x = yy.x > 0.f ? acc.x : 0.f;
-        acc.y = yy.y > 0.f ? acc.y : 0.f;
-        acc.z = yy.z > 0.f ? acc.z : 0.f;
-        acc.w = yy.w > 0.f ? acc.w : 0.f;
         *reinterpret_cast<float4*>(dy + pix * C + g * 4) = acc;
         accb[0][0] += (double)acc.x; accb[0][1] += (double)acc.y; accb[0][2] += (double)acc.z; accb[0][3] += (double)acc.w;
     }
@@ -343,7 +339,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
 __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restrict__ dz, const float* __restrict__ p,
-                                                           const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                                           const uint8_t* __restrict__ idx,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
                                                            __hip_bfloat16* __restrict__ dy_pad,
                                                            double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C,
@@ -368,25 +364,48 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
         const float* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
         const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + ((int64_t)n * ccn + sl) * Hp * Wp * CS + l8 * 4;                            // slice-major, see idx_off
-        const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
         float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
         __hip_bfloat16* dpn = dy_pad ? dy_pad + (int64_t)n * (Hc + 2) * (Wc + 2) * C + c0 : nullptr;
         __syncthreads();
-        for (int h = h0 > 2 ? h0 - 2 : 0; h < h1; ++h) {     // dy row h gathers from pooled rows h-2..h: two warm-up rows
-            if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
-                for (int x = px; x < Wp; x += 32) {
-                    const int64_t o = ((int64_t)h * Wp + x) * C;
-                    const float4 d = *reinterpret_cast<const float4*>(dzn + o);
-                    const float4 q = *reinterpret_cast<const float4*>(pn + o);
-                    float4 v;
-                    v.x = fmaf(ca.x, d.x, fmaf(cbv.x, q.x, cc.x));
-                    v.y = fmaf(ca.y, d.y, fmaf(cbv.y, q.y, cc.y));
-                    v.z = fmaf(ca.z, d.z, fmaf(cbv.z, q.z, cc.z));
-                    v.w = fmaf(ca.w, d.w, fmaf(cbv.w, q.w, cc.w));
-                    *reinterpret_cast<float4*>(&smem[(((h % 3) * Wp) + x) * CS + l8 * 4]) = v;
-                    sidx[(((h % 3) * Wp) + x) * 8 + l8] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)h * Wp + x) * CS);
+        // Software pipeline over rows: the loads of pooled row h+1 (dz, p, argmax) are issued into registers before row h is
+        // gathered and land while it is computed. Without it every row paid a full global-load round trip between two
+        // barriers: ~9 MB in flight chip-wide = 3.6 TB/s, which is what the kernel measured.
+        constexpr int MAXP = 5;                                  // passes of 32 pixels: Wp <= 136 by the LDS limit of the launcher
+        float4 rd[MAXP], rq[MAXP];
+        uint32_t ri[MAXP];
+        const int hfirst = h0 > 2 ? h0 - 2 : 0;                  // dy row h gathers from pooled rows h-2..h: two warm-up rows
+        auto prefetch = [&](int hr) {
+#pragma unroll
+            for (int ps = 0; ps < MAXP; ++ps) {
+                const int x = px + 32 * ps;
+                if (hr < Hp && x < Wp) {
+                    const int64_t o = ((int64_t)hr * Wp + x) * C;
+                    rd[ps] = *reinterpret_cast<const float4*>(dzn + o);
+                    rq[ps] = *reinterpret_cast<const float4*>(pn + o);
+                    ri[ps] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)hr * Wp + x) * CS);
                 }
             }
+        };
+        prefetch(hfirst);
+        for (int h = hfirst; h < h1; ++h) {
+            if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
+#pragma unroll
+                for (int ps = 0; ps < MAXP; ++ps) {
+                    const int x = px + 32 * ps;
+                    if (x < Wp) {
+                        const float4 d = rd[ps], q = rq[ps];
+                        float4 v;
+                        // the ReLU mask rides on p: every window whose argmax is a given conv pixel has p equal to that pixel's y
+                        v.x = q.x > 0.f ? fmaf(ca.x, d.x, fmaf(cbv.x, q.x, cc.x)) : 0.f;
+                        v.y = q.y > 0.f ? fmaf(ca.y, d.y, fmaf(cbv.y, q.y, cc.y)) : 0.f;
+                        v.z = q.z > 0.f ? fmaf(ca.z, d.z, fmaf(cbv.z, q.z, cc.z)) : 0.f;
+                        v.w = q.w > 0.f ? fmaf(ca.w, d.w, fmaf(cbv.w, q.w, cc.w)) : 0.f;
+                        *reinterpret_cast<float4*>(&smem[(((h % 3) * Wp) + x) * CS + l8 * 4]) = v;
+                        sidx[(((h % 3) * Wp) + x) * 8 + l8] = ri[ps];
+                    }
+                }
+            }
+            if (h + 1 < h1) prefetch(h + 1);
             __syncthreads();
             for (int w = px; w < Wc && h >= h0; w += 32) {
                 float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -409,11 +428,6 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
                     }
                 }
                 const int64_t o = ((int64_t)h * Wc + w) * C;
-                const float4 yy = *reinterpret_cast<const float4*>(yn + o);
-                a4.x = yy.x > 0.f ? a4.x : 0.f;
-                a4.y = yy.y > 0.f ? a4.y : 0.f;
-                a4.z = yy.z > 0.f ? a4.z : 0.f;
-                a4.w = yy.w > 0.f ? a4.w : 0.f;
                 if (dyn) *reinterpret_cast<float4*>(dyn + o) = a4;
                 if (dpn)
                     *reinterpret_cast<uint2*>(dpn + ((int64_t)(h + 1) * (Wc + 2) + w + 1) * C) =
@@ -507,38 +521,38 @@ int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gam
     return 0;
 }
 
-int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                        float* dy, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C, void* stream) {
-    GN_REQUIRE(dz && p && idx && y && coef3 && dy && dbias_partials, GOALNET_E_NULL, "bnpool_bwd: null pointer");
+    GN_REQUIRE(dz && p && idx && coef3 && dy && dbias_partials, GOALNET_E_NULL, "bnpool_bwd: null pointer");
     GN_PARTS_OK("bnpool_bwd");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd: bad dims");
-    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) &&
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd: alignment");
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
-        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, coef3,
                            dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
     } else {
-        hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, y, coef3, dy,
+        hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("bnpool_bwd");
     return 0;
 }
 
-int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                              void* stream) {
-    GN_REQUIRE(dz && p && idx && y && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p: null pointer");
+    GN_REQUIRE(dz && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p: null pointer");
     GN_PARTS_OK("bnpool_bwd_bf16p");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: bad dims (C %% 32)");
-    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(y) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p: alignment");
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, y, coef3,
+    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, coef3,
                        dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;

@@ -143,18 +143,18 @@ def bn_bwd_finalize(partials, gamma, mean, invstd, count, C, dgamma, dbeta, coef
                                         dgamma.data_ptr(), dbeta.data_ptr(), coef3.data_ptr(), _s()), "bn_bwd_finalize")
 
 
-def bnpool_bwd(dz, p, idx, y, coef3, dy, dbias_partials, N, Hc, Wc, C):
-    _chk(dz, p, idx, y, coef3, dy, dbias_partials)
+def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
+    _chk(dz, p, idx, coef3, dy, dbias_partials)
     npool = N * (Hc - 2) * (Wc - 2) * C
-    assert dz.numel() == p.numel() == idx.numel() == npool and y.numel() == dy.numel() == N * Hc * Wc * C
-    check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
+    assert dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C
+    check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
                                    dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd")
 
 
-def bnpool_bwd_bf16p(dz, p, idx, y, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
-    _chk(dz, p, idx, y, coef3, dy, dypad, dbias_partials)
+def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
+    _chk(dz, p, idx, coef3, dy, dypad, dbias_partials)
     assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
-    check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), y.data_ptr(), coef3.data_ptr(), _p(dy),
+    check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
                                          dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
           "bnpool_bwd_bf16p")
 

@@ -85,14 +85,15 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
 /* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
 int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
-/* phase 3, fused: BN backward apply -> max-pool backward (gather by argmax) -> ReLU backward.
+/* phase 3, fused: BN backward apply -> max-pool backward (gather by argmax) -> ReLU backward. The conv output y is not
+ * an operand: a window whose argmax is a given pixel has p equal to that pixel's y, so the ReLU mask (y > 0) is read off p.
  * dy[N][Hc][Wc][C] = grad wrt the conv's pre-ReLU output; dbias_partials (double
  * [nparts][C]) = per-block column sums of dy. */
-int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                        float* dy, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C, void* stream);
 /* same, writing dy as bf16 into the zero-padded layout of goalnet_to_bf16_padded (dy_pad_bf16 = padded pixel 0);
  * the fp32 dy is optional (NULL when only the bf16 GEMMs consume it). */
-int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* y, const float* coef3,
+int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                              void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */

@@ -95,12 +95,12 @@ def pool_case(name, hc, wc, c):
     dz = torch.randn(n, hp, wp, c, device=dev); coef3 = torch.randn(3 * c, device=dev)
     dparts = torch.empty(parts * c, dtype=torch.float64, device=dev)
     dy = torch.empty(n, hc, wc, c, device=dev)
-    t, ta = timeit(lambda: ops.bnpool_bwd(dz, p, idx, y, coef3, dy, dparts, n, hc, wc, c))
-    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 8) / 1e9
+    t, ta = timeit(lambda: ops.bnpool_bwd(dz, p, idx, coef3, dy, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 4) / 1e9
     print(f"{name} bnpool bwd (fp32 dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
     bd, dyp = ops.padded_bf16_alloc(n, hc, wc, c, dev)
-    t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dz, p, idx, y, coef3, None, dyp, dparts, n, hc, wc, c))
-    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 6) / 1e9
+    t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dz, p, idx, coef3, None, dyp, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 2) / 1e9
     print(f"{name} bnpool bwd (bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
 
 

@@ -193,7 +193,7 @@ def test_pool_bn_forward_and_backward(n, hc, wc, c, parts):
     ops.bn_bwd_finalize(partials, gamma.to(DEV), st[0], st[1], n * hp * wp, c, dgamma, dbeta, coef3)
     dy = torch.empty(n, hc, wc, c, device=DEV)
     dparts = torch.empty(parts * c, dtype=torch.float64, device=DEV)
-    ops.bnpool_bwd(dbn, p, idx, yg, coef3, dy, dparts, n, hc, wc, c)
+    ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
     dbias = torch.empty(c, device=DEV)
     ops.partials_sum(dparts, parts, c, c, dbias)
     close("bn.dgamma", dgamma, gd.grad, rtol=5e-6)
