@@ -44,12 +44,13 @@ __device__ __forceinline__ int tile_row_of(int h, int lr) { return (lr / GROUP) 
 // K-contiguous bf16 matrix X[rows][K] (weights [Cout][9*Cin]); wave w issues pieces 2w, 2w+1 of a half-tile
 template <int GROUP>
 struct KCLoader256 {
-    struct P { const __hip_bfloat16* x; int64_t ld; int rows; };
+    struct P { const __hip_bfloat16* x; int64_t ld; int rows; int convC; };      // convC > 0: K-tiles in (channel chunk, tap) order
     static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
-    int wave;
+    int wave, convC;
     __device__ KCLoader256(const P& p, int row0, int tid) {
+        convC = p.convC;
         const int nrows = p.rows - row0 < T ? p.rows - row0 : T;
         rx = make_rsrc(p.x + (int64_t)row0 * p.ld, clamp_u32((int64_t)nrows * p.ld * 2));
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,8 +66,10 @@ struct KCLoader256 {
             }
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
+        // the k range of K-tile kt: plain = [64 kt, +64); convolution order = tap (kt % 9), channels 64 (kt / 9) .. +63
+        const unsigned koff = convC > 0 ? (unsigned)((kt % 9) * convC + (kt / 9) * BKH) : (unsigned)kt * BKH;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], (unsigned)kt * ROWB);
+        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], koff * 2);
     }
 };
 
@@ -78,10 +81,9 @@ struct ConvAPadLoader256 {
     static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
-    int Wp2, C, lgC, wave;
+    int Wp2, C, wave;
     __device__ ConvAPadLoader256(const P& p, int row0, int tid) {
         Wp2 = p.W + 2; C = p.C;
-        lgC = (p.C & (p.C - 1)) == 0 ? 31 - __builtin_clz(p.C) : -1;       // channel counts here are powers of two: no division per K-tile
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
         const int hw = p.H * p.W;
@@ -108,12 +110,14 @@ struct ConvAPadLoader256 {
             }
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
-        const int k = kt * BKH;
-        const int tap = lgC >= 0 ? k >> lgC : k / C;
-        const int ci = k - tap * C;
+        // K-tile order = (64-channel chunk, tap): the nine taps of one chunk touch almost the same pixels, so they re-hit
+        // L2. With taps outermost the reuse distance was a whole sweep over the channels of every resident block (8 MB per
+        // XCD at C = 512) and the data gradient re-fetched its input 5x from the fabric (profiles/r01_bf16_traffic.md).
+        const int chunk = kt / 9, tap = kt - 9 * chunk;
+        const int ci = chunk * BKH;
         const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                  // tap / 3 for tap < 16
-        // past the last K-tile (tap >= 9) the offset only has to stay harmless: the range check turns it into zeros
-        const unsigned s0 = tap < 9 ? (unsigned)(((kh * Wp2 + kw) * C + ci) * 2) : OOB;
+        // past the last K-tile (ci >= C) the offset only has to stay harmless: the range check turns it into zeros
+        const unsigned s0 = ci < C ? (unsigned)(((kh * Wp2 + kw) * C + ci) * 2) : OOB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], s0);
     }
@@ -240,13 +244,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     constexpr bool TRF = AL::TR;
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
-    int tm, tn;
-    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
+    int tm, tn, split = 0;
+    if (ROLE == 2) {
+        // weight gradient: few output tiles (18), many K splits. All tiles of a split read the same pixels, so they run on
+        // ONE XCD back to back (blocks L, L + 8, ... share an XCD): XCD x takes splits x, x + 8, ... and walks their tiles.
+        // Spread over all XCDs, every XCD fetched every pixel: 72 GB/launch from the fabric against 9 GB of operands.
+        const int tiles = tiles_m * tiles_n, nsplit = (int)gridDim.x / tiles;
+        const int L = (int)blockIdx.x, xcd = L & 7, j = L >> 3;
+        if ((nsplit & 7) == 0) { split = xcd + 8 * (j / tiles); const int t = j % tiles; tm = t % tiles_m; tn = t / tiles_m; }
+        else { split = L / tiles; const int t = L % tiles; tm = t % tiles_m; tn = t / tiles_m; }
+    } else {
+        tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
+    }
     const AL al(ap, tm * T, tid);
     const BL bl(bp, tn * T, tid);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int kt0 = blockIdx.y * ktiles_per_split;                      // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
+    const int kt0 = split * ktiles_per_split;                           // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
     const int ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
 
     f32x16 acc[4][2];
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // epilogue (conv forward: bias + ReLU; data gradient: raw; weight gradient: raw split-K slab)
     const int r = lane & 31, hh = lane >> 5;
     const bool brelu = ep.mode == EPI_BIAS_RELU && ep.slab_stride == 0;
-    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)blockIdx.y * ep.slab_stride : 0);
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -357,7 +371,7 @@ static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_p
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     AL::P ap{x_pad, H, W, Cin, M};
-    BL::P bp{w, (int64_t)9 * Cin, Cout};
+    BL::P bp{w, (int64_t)9 * Cin, Cout, Cin};
     hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
                        (int)tiles_m, (int)tiles_n, 0, 9 * Cin / BKH, 9 * Cin / BKH);
     GN_LAUNCH_CHECK(name);
@@ -403,7 +417,8 @@ int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const _
     AL::P ap{dy_pad, Cout, Cout, Mp};
     BL::P bp{x_pad, Wp2, Cin, Mp};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 2>), dim3((unsigned)(tiles_m * tiles_n), (unsigned)nsplit), dim3(512), LDS_BYTES, st,
+    GN_REQUIRE(tiles_m * tiles_n * nsplit < (1ll << 31), GOALNET_E_SHAPE, "%s: too many blocks", name);
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 2>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
                        ap, bp, ep, (int)tiles_m, (int)tiles_n, 1, ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
