@@ -461,3 +461,38 @@ def test_linear_bwd_bf16(m, k, j, use_mult):
     dw = torch.full((j, k), float("nan"), device=DEV)
     ops.linear_bwd_dw_bf16(dy.to(DEV), x.to(DEV), dw)
     close(f"linear_bwd_dw_bf16[{m}: {j}x{k}]", dw, dy.double().t() @ x.double(), rtol=3e-6)
+
+
+def test_phased_256_kernels_at_the_sizes_that_select_them(monkeypatch):
+    """At bench-like sizes the entry points pick the 256 x 256 phased kernels by themselves (M >= 65 536 pixels for
+    forward / data gradient, >= 262 144 padded pixels for the weight gradient). Same operands through the 128 x 128
+    kernels (forced) must agree to fp32 summation-order noise."""
+    n, h, w, cin, cout = 49, 72, 72, 256, 512                            # conv3 of the 224 x 224 model, 49 frames
+    g = torch.Generator().manual_seed(70)
+    x = (torch.rand(n, h, w, cin, generator=g) - 0.5).to(DEV)
+    dy = (torch.rand(n, h, w, cout, generator=g) - 0.5).to(DEV)
+    wt = ((torch.rand(cout, 3, 3, cin, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    b = (torch.rand(cout, generator=g) - 0.5).to(DEV)
+    wflip = torch.empty(cout * 9 * cin, device=DEV)
+    ops.conv3x3_weight_flip(wt.float().contiguous(), wflip, cout, cin)
+    wflip = wflip.to(torch.bfloat16)
+    _, xp = _padded(x)
+    _, dyp = _padded(dy)
+    out = {}
+    for tile in ("auto", "128"):
+        if tile == "auto":
+            monkeypatch.delenv("GOALNET_BF16_TILE", raising=False)
+        else:
+            monkeypatch.setenv("GOALNET_BF16_TILE", tile)
+        y = torch.empty(n, h, w, cout, device=DEV)
+        ops.conv3x3_fwd_bf16p(xp, wt, b, True, y, n, h, w, cin, cout)
+        dx = torch.empty(n, h, w, cin, device=DEV)
+        ops.conv3x3_fwd_bf16p(dyp, wflip, None, False, dx, n, h, w, cout, cin)
+        dw = torch.empty(cout, 3, 3, cin, device=DEV)
+        ops.conv3x3_wgrad_bf16(xp, dyp, dw, n, h, w, cin, cout)
+        out[tile] = (y, dx, dw)
+    for name, a, r in zip(("forward", "data gradient", "weight gradient"), out["auto"], out["128"]):
+        scale = r.abs().max().item()
+        err = (a - r).abs().max().item()
+        print(f"[parity] conv3 {name}: 256-tile vs 128-tile max |diff| {err:.3e} (max |ref| {scale:.3e})")
+        assert err <= 2e-5 * scale, name
