@@ -452,6 +452,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
+// Few outputs, many slabs (the weight-streaming forward at <= 16 rows: 5 120 outputs x 81 slabs): 16 lanes (a DPP row) share
+// one float4 of output, lane g sums slabs g, g+16, ...; row16_sum adds the 16 partial sums in a fixed order.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* slabs, int nsplit, int64_t slab_stride, EpiP ep) {
+    const int c4n = ep.cols >> 2;
+    const int64_t total = (int64_t)ep.rows * c4n;
+    const int g = threadIdx.x & 15;
+    const int64_t step = (int64_t)gridDim.x * 16;
+    const int64_t rounds = (total + step - 1) / step;                 // whole DPP rows stay together
+    int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    for (int64_t r = 0; r < rounds; ++r, i += step) {
+        const bool ok = i < total;
+        const int64_t ic = ok ? i : 0;
+        const int64_t row = ic / c4n;
+        const int col = (int)(ic - row * c4n) * 4;
+        const float* s = slabs + row * ep.cols + col;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = g; k < nsplit; k += 16) {
+            const float4 b = *reinterpret_cast<const float4*>(s + (int64_t)k * slab_stride);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        a.x = row16_sum(a.x); a.y = row16_sum(a.y); a.z = row16_sum(a.z); a.w = row16_sum(a.w);
+        if (ok && g == 0) {
+            float* o = ep.out + row * ep.ld + col;
+            o[0] = epi_apply(ep, a.x, row, col);
+            o[1] = epi_apply(ep, a.y, row, col + 1);
+            o[2] = epi_apply(ep, a.z, row, col + 2);
+            o[3] = epi_apply(ep, a.w, row, col + 3);
+        }
+    }
+}
+
 template <class AL, class BL>
 int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
                 int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, hipStream_t st) {
@@ -474,6 +505,13 @@ int launch_splitk_reduce(const char* name, const float* slabs, int nsplit, int64
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
+    if (total < 65536 && nsplit >= 32) {
+        int64_t wb = (total + 15) / 16;
+        if (wb > 4096) wb = 4096;
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)wb), dim3(256), 0, st, slabs, nsplit, slab_stride, ep);
+        GN_LAUNCH_CHECK(name);
+        return 0;
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slabs, nsplit, slab_stride, ep);
     GN_LAUNCH_CHECK(name);
     return 0;

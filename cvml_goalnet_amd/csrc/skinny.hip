@@ -26,6 +26,19 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     __shared__ float xs[MR * KT];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t k0 = (int64_t)blockIdx.y * KT;
+    // all weight loads of the block (two rounds of 4 columns x KT) are issued first: they do not depend on x, and the HBM
+    // round trip then overlaps the staging of the x slab instead of following it
+    float4 w4[JB / 16][KT / 256][4];
+#pragma unroll
+    for (int rnd = 0; rnd < JB / 16; ++rnd)
+#pragma unroll
+        for (int kk = 0; kk < KT / 256; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = blockIdx.x * JB + rnd * 16 + wv * 4 + jj;
+                const int64_t k = k0 + kk * 256 + lane * 4;
+                w4[rnd][kk][jj] = (j < J && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     // stage the x slab (BatchNorm affine folded in, zero beyond M / K)
     for (int i = tid; i < MR * (KT / 4); i += 256) {
         const int m = i / (KT / 4), kq = i % (KT / 4);
@@ -42,7 +55,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(&xs[m * KT + kq * 4]) = v;
     }
     __syncthreads();
-#pragma unroll 1
+#pragma unroll
     for (int rnd = 0; rnd < JB / 16; ++rnd) {
         const int j0 = blockIdx.x * JB + rnd * 16 + wv * 4;
         float acc[4][MR];
@@ -50,15 +63,6 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int m = 0; m < MR; ++m) acc[jj][m] = 0.f;
-        float4 w4[KT / 256][4];
-#pragma unroll
-        for (int kk = 0; kk < KT / 256; ++kk)         // all weight loads of the round are in flight before the first FMA
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = j0 + jj;
-                const int64_t k = k0 + kk * 256 + lane * 4;
-                w4[kk][jj] = (j < J && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
 #pragma unroll
         for (int kk = 0; kk < KT / 256; ++kk) {
             const int kl = kk * 256 + lane * 4;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
             for (int m = 0; m < MR; ++m) {
                 const float4 x4 = *reinterpret_cast<const float4*>(&xs[m * KT + kl]);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[jj][m] += dot4(w4[kk][jj], x4);
+                for (int jj = 0; jj < 4; ++jj) acc[jj][m] += dot4(w4[rnd][kk][jj], x4);
             }
         }
         // lane jj * MR + m keeps the total of (column j0 + jj, row m): one parallel epilogue instead of 4 * MR serial ones
