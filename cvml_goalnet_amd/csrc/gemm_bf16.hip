@@ -521,9 +521,16 @@ static int linear_splits_h(int M, int64_t K, int J) {
     return pick_splits(tiles, (int)(K / BKH));
 }
 
+// many rows and a long reduction (linear5 at the bench shape): the 256 x 256 phased kernel with XCD-local K-splits
+static bool linear_use_256(int M, int64_t K, int J) {
+    const char* forced = getenv("GOALNET_BF16_TILE");
+    return forced ? forced[0] == '2' : (M >= 512 && J >= 256 && K >= (1ll << 18));
+}
+
 size_t goalnet_linear_fwd_bf16_ws_bytes(int M, int64_t K, int J) {
     if (M <= 0 || K <= 0 || J <= 0) return 0;
-    const int s = linear_splits_h(M, K, J);
+    const int a = linear_splits_h(M, K, J), b = linear_fwd_splits_256(M, K, J);     // enough for either kernel
+    const int s = a > b ? a : b;
     return s > 1 ? (size_t)s * (size_t)M * (size_t)J * sizeof(float) : 0;
 }
 
@@ -535,6 +542,18 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
     GN_REQUIRE(K % BKH == 0 && J % 4 == 0 && ldx % 8 == 0 && ldy % 4 == 0, GOALNET_E_SHAPE, "linear_fwd_bf16: K %% 64, J %% 4, ldx %% 8");
     GN_REQUIRE(aligned16(x_bf16) && aligned16(w_bf16) && aligned16(y), GOALNET_E_ALIGN, "linear_fwd_bf16: alignment");
     hipStream_t st = (hipStream_t)stream;
+    if (linear_use_256(M, K, J)) {
+        const int ns = linear_fwd_splits_256(M, K, J);
+        if (ns > 1) {
+            GN_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)ns * (size_t)M * (size_t)J * sizeof(float), GOALNET_E_WORKSPACE,
+                       "linear_fwd_bf16: workspace too small");
+            const EpiP efin{(dropmask || mult_out) ? EPI_FULL : EPI_BIAS_RELU, y, ldy, M, J, bias, relu, dropmask, ldmask, mult_out, ldmult, 0};
+            const int rc2 = launch_linear_fwd_bf16_256("linear_fwd_bf16(256)", (const __hip_bfloat16*)x_bf16, ldx, (const __hip_bfloat16*)w_bf16,
+                                                       M, K, J, (float*)ws, ns, st);
+            if (rc2) return rc2;
+            return launch_splitk_reduce("linear_fwd_bf16(256).reduce", (const float*)ws, ns, (int64_t)M * J, efin, st);
+        }
+    }
     const int nsplit = linear_splits_h(M, K, J);
     KCLoaderH::P ap{(const __hip_bfloat16*)x_bf16, ldx, M};
     KCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, K, J};
@@ -676,6 +695,9 @@ int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: bad dims");
     GN_REQUIRE(J % BKH == 0 && K % 8 == 0 && lddy % 8 == 0 && lddx % 4 == 0, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: J %% 64, K %% 8");
     GN_REQUIRE(aligned16(dy_bf16) && aligned16(w_bf16) && aligned16(dx), GOALNET_E_ALIGN, "linear_bwd_dx_bf16: alignment");
+    if (!mult && linear_use_256(M, K, J))
+        return launch_linear_dx_bf16_256("linear_bwd_dx_bf16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)w_bf16, M, K,
+                                         J, dx, lddx, (hipStream_t)stream);
     KCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, K, (int)K, J};
     EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};

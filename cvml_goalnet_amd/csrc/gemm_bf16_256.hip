@@ -240,13 +240,12 @@ template <class AL, class BL, int ROLE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                               int tiles_m, int tiles_n, int m_fast, int ktiles_total,
                                                               int ktiles_per_split) {
-    static_assert(AL::TR == BL::TR, "both operands K-contiguous or both row-contiguous");
-    constexpr bool TRF = AL::TR;
+    constexpr bool TRA = AL::TR, TRB = BL::TR;      // operand forms: K-contiguous rows (false) or row-contiguous / transposed-read (true)
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
     int tm, tn, split = 0;
-    if (ROLE == 2) {
-        // weight gradient: few output tiles (18), many K splits. All tiles of a split read the same pixels, so they run on
+    if (ROLE == 2 || ROLE == 3) {
+        // weight gradient (and the linear5 forward): few output tiles (18 / 8), many K splits. All tiles of a split read the same pixels, so they run on
         // ONE XCD back to back (blocks L, L + 8, ... share an XCD): XCD x takes splits x, x + 8, ... and walks their tiles.
         // Spread over all XCDs, every XCD fetched every pixel: 72 GB/launch from the fabric against 9 GB of operands.
         const int tiles = tiles_m * tiles_n, nsplit = (int)gridDim.x / tiles;
@@ -284,10 +283,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // 8 ds_read_b128 per wave (8 | 4 | 8 | 4) and the LDS time of a phase stays within one MFMA section.
     bf16x8 a[2][4], bx[4], by[4];
     auto rdA = [&](const char* half, int f, int ks) -> bf16x8 {
-        return TRF ? read_frag_tr(half, 2 * wr + f, ks, lane) : read_frag(half, wr * 64 + f * 32, ks, lane);
+        return TRA ? read_frag_tr(half, 2 * wr + f, ks, lane) : read_frag(half, wr * 64 + f * 32, ks, lane);
     };
     auto rdB = [&](const char* half, int ks) -> bf16x8 {
-        return TRF ? read_frag_tr(half, wc, ks, lane) : read_frag(half, wc * 32, ks, lane);
+        return TRB ? read_frag_tr(half, wc, ks, lane) : read_frag(half, wc * 32, ks, lane);
     };
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bx[ks] = rdB(slot(0, 2), ks);
@@ -338,14 +337,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int col = tn * T + (TRF ? ni * 128 + 16 * wc + (r & 15) + 64 * (r >> 4) : wc * 64 + ni * 32 + r);
+            const int col = tn * T + (TRB ? ni * 128 + 16 * wc + (r & 15) + 64 * (r >> 4) : wc * 64 + ni * 32 + r);
             const bool colok = col < ep.cols;
             const float bv = (brelu && ep.bias && colok) ? ep.bias[col] : 0.f;
             const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const int64_t row = (int64_t)tm * T + (TRF ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (i & 15) + 64 * (i >> 4)
+                const int64_t row = (int64_t)tm * T + (TRA ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (i & 15) + 64 * (i >> 4)
                                                            : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + i);
                 if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[mi][ni][e] + bv, lo);
             }
@@ -397,6 +396,66 @@ int wgrad_splits_256(int64_t Mp, int Cin, int Cout) {
     if (s > 1024) s = 1024;
     const int kps = (int)((ktiles + s - 1) / s);
     return (ktiles + kps - 1) / kps;
+}
+
+static int splits_for_256(int64_t tiles, int ktiles) {
+    int64_t s = (1024 + tiles - 1) / tiles;
+    const int64_t smax = ktiles / 64 > 1 ? ktiles / 64 : 1;             // >= 64 K-tiles per split
+    if (s > smax) s = smax;
+    if (s >= 8) s = (s + 7) / 8 * 8;                                    // whole XCD groups
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    const int kps = (int)((ktiles + s - 1) / s);
+    return (ktiles + kps - 1) / kps;
+}
+
+int linear_fwd_splits_256(int M, int64_t K, int J) {
+    return splits_for_256((int64_t)((M + T - 1) / T) * ((J + T - 1) / T), (int)(K / BKH));
+}
+
+// y_slabs[split][M][J] (fp32) = partial sums of x[M][K] . w[J][K]^T over the split's K range; the caller reduces + epilogue
+int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_t ldx, const __hip_bfloat16* w, int M, int64_t K,
+                               int J, float* slabs, int nsplit, hipStream_t st) {
+    typedef KCLoader256<64> AL;
+    typedef KCLoader256<32> BL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (J + T - 1) / T;
+    const int ktiles = (int)(K / BKH);
+    const int kps = (ktiles + nsplit - 1) / nsplit;
+    AL::P ap{x, ldx, M, 0};
+    BL::P bp{w, K, J, 0};
+    EpiP ep{EPI_RAW, slabs, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 3>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
+                       ap, bp, ep, (int)tiles_m, (int)tiles_n, 1, ktiles, kps);
+    GN_LAUNCH_CHECK(name);
+    return 0;
+}
+
+// dx[M][K] (fp32) = dy[M][J] . w[J][K]: A K-contiguous (reduction index j), B row-contiguous; no split (J / 64 K-tiles)
+int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
+                              int J, float* dx, int64_t lddx, hipStream_t st) {
+    typedef KCLoader256<64> AL;
+    typedef MCLoader256 BL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (K + T - 1) / T;
+    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
+    AL::P ap{dy, lddy, M, 0};
+    BL::P bp{w, K, (int)K, J};
+    EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 4>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
+                       (int)tiles_m, (int)tiles_n, 1, J / BKH, J / BKH);
+    GN_LAUNCH_CHECK(name);
+    return 0;
 }
 
 // conv 3x3 weight gradient on the zero-padded pixel grid: slabs[split][Cout][9*Cin] (fp32), reduced by the caller

@@ -33,6 +33,11 @@ int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, i
                          int Cout, const EpiP& ep, hipStream_t st);
 
 int wgrad_splits_256(int64_t Mp, int Cin, int Cout);
+int linear_fwd_splits_256(int M, int64_t K, int J);
+int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_t ldx, const __hip_bfloat16* w, int M, int64_t K,
+                               int J, float* slabs, int nsplit, hipStream_t st);
+int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
+                              int J, float* dx, int64_t lddx, hipStream_t st);
 int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
                           int64_t Mp, float* slabs, int nsplit, hipStream_t st);
 

@@ -380,8 +380,10 @@ def test_conv3x3_fwd_bf16(n, h, w, cin, cout, bias, relu):
     close(f"conv3x3_fwd_bf16[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)
 
 
-@pytest.mark.parametrize("m,k,j", [(10, 41472, 512), (37, 640, 512), (130, 512, 256)])
-def test_linear_fwd_bf16(m, k, j):
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("m,k,j", [(10, 41472, 512), (37, 640, 512), (130, 512, 256), (300, 8192, 320)])
+def test_linear_fwd_bf16(m, k, j, tile, monkeypatch):
+    monkeypatch.setenv("GOALNET_BF16_TILE", tile)
     x = rnd(m, k, seed=56).to(torch.bfloat16)
     w = rnd(j, k, seed=57, lo=-0.05, hi=0.05).to(torch.bfloat16)
     b = rnd(j, seed=58)
@@ -446,8 +448,10 @@ def test_conv3x3_wgrad_bf16(n, h, w, cin, cout, tile, monkeypatch):
     close(f"conv3x3_wgrad_bf16[{n}x{h}x{w}x{cin}->{cout}]", dw, ref.permute(0, 2, 3, 1), rtol=5e-6)
 
 
-@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True)])
-def test_linear_bwd_bf16(m, k, j, use_mult):
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("m,k,j,use_mult", [(10, 41472, 512, False), (37, 640, 512, True), (130, 512, 256, True), (300, 4168, 320, False)])
+def test_linear_bwd_bf16(m, k, j, use_mult, tile, monkeypatch):
+    monkeypatch.setenv("GOALNET_BF16_TILE", tile)
     dy = rnd(m, j, seed=68).to(torch.bfloat16)
     w = rnd(j, k, seed=69, lo=-0.05, hi=0.05).to(torch.bfloat16)
     x = rnd(m, k, seed=70).to(torch.bfloat16)
