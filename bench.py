@@ -140,7 +140,33 @@ def native40_loop(dev, frames=300, videos=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = videos * ((frames + 9) // 10)
-    return {"frames_per_s": videos * frames / dt, "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
+    # the same 10-frame train step by the CPU oracle on this host's cores (what the reference's own loop costs per step)
+    cpu_us, cpu_threads = None, None
+    try:
+        from oracle import avm_ref
+        sd = model.state_dict()
+        p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+        b = {k: v.clone() for k, v in sd.items() if k not in p}
+        a_c, v_c, l_c = aud[:10].cpu(), vis[:10].cpu(), lab[:10].cpu()
+        masks = [torch.from_numpy(m) for m in synth.make_drop_masks(10, step=0)]
+        best = None
+        all_threads = torch.get_num_threads()
+        for th in sorted({8, all_threads}):              # small tensors: more threads are not faster; report the better setting
+            torch.set_num_threads(th)
+            state, ts = {}, []
+            pp = {k: v.clone() for k, v in p.items()}
+            bb = {k: v.clone() for k, v in b.items()}
+            for _ in range(5):
+                t1 = time.perf_counter()
+                avm_ref.train_step(pp, bb, state, a_c, v_c, l_c, masks, True)
+                ts.append(time.perf_counter() - t1)
+            if best is None or min(ts[1:]) < best[0]:
+                best = (min(ts[1:]), th)
+        torch.set_num_threads(all_threads)
+        cpu_us, cpu_threads = 1e6 * best[0], best[1]
+    except Exception as e:
+        log(f"cpu oracle at 40x40 failed: {e!r}")
+    return {"frames_per_s": videos * frames / dt, "cpu_oracle_us_per_step": cpu_us, "cpu_threads": cpu_threads, "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
             "dtype": "f32", "mode": "one HIP graph launch per sub-batch (loop.VideoTrainer)", "graph_replays": tr.replays,
             "eager_steps": tr.eager_steps, "videos": videos, "frames_per_video": frames, "last_batch_loss": batch_loss}
 
