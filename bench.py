@@ -20,6 +20,8 @@ Extra objects on the JSON line:
                 bounded sample (1 clip = 16 frames of 224x224 per step), rank 0, N = 1 only.
   parity        logit MAE / max-abs of the HIP forward vs that CPU reference on the same 16 frames and weights: on the
                 random-init weights before the first optimizer step, and again on the weights the timed steps left.
+  roofline_fp32_path  (bf16 runs, N = 1 only) the same workload with precision="fp32" — the reference's arithmetic on the
+                fp32 matrix cores — so that the line carries the fp32-MFMA roofline of the conv forward next to the bf16 one.
   native_40x40_loop  SURVEY.md §8(d) "report additionally frames/s at the reference-native 40x40": the reference's own
                 operating point (main.py:169-198: one video at a time, 10 frames per optimizer step, fp32), run by
                 loop.VideoTrainer as one HIP-graph launch per sub-batch; N = 1 only, a few seconds.
@@ -120,6 +122,34 @@ def cpu_baseline(model, h, w, seed, max_seconds=40.0):
     return {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
             "sample": f"oracle train step (fwd+MSE+bwd+Adam) on {n} frames (1 clip) of {h}x{w}, fp32, torch {torch.__version__} CPU, "
                       f"{len(times)} steps, best of the non-first: {t:.2f} s/step"}
+
+
+def fp32_path_roofline(dev, n, h, w, audio, seed):
+    """The same step on the reference's own arithmetic (precision="fp32": fp32 MFMA, `v_mfma_f32_32x32x2_f32`): two timed
+    steps, conv2 + conv3 forward launches bracketed with HIP events exactly as for the main roofline object."""
+    from cvml_goalnet_amd import AVM
+    model = AVM(audio_included=audio, device=dev, seed=seed, precision="fp32")
+    aud, vis, lab = make_inputs(n, h, w, dev, seed)
+    if not audio:
+        aud = None
+    for _ in range(2):
+        model.train_step(aud, vis, lab)
+    model.kernel_events = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        model.train_step(aud, vis, lab)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    ev = model.kernel_events["conv_fwd"]
+    model.kernel_events = None
+    ms = [a.elapsed_time(b) for a, b, _ in ev]
+    fl = [f for _, _, f in ev]
+    achieved = sum(fl) / (sum(ms) * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "kernel": "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)",
+            "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms), "ms_per_step": 1e3 * dt,
+            "clips_per_s": (n / FRAMES_PER_CLIP) / dt, "dtype": "f32"}
 
 
 def native40_loop(dev, frames=300, videos=3):
@@ -307,6 +337,10 @@ def main():
             try:
                 del model, aud, vis, lab
                 torch.cuda.empty_cache()
+                if args.dtype == "bf16":
+                    # the reference is fp32: the same workload on the fp32 matrix cores, for the fp32-MFMA roofline
+                    res["roofline_fp32_path"] = fp32_path_roofline(dev, n, h, w, not args.no_audio, seed)
+                    torch.cuda.empty_cache()
                 res["native_40x40_loop"] = native40_loop(dev)
             except Exception as e:
                 log(f"native 40x40 loop failed: {e!r}")
