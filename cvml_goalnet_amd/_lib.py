@@ -78,6 +78,8 @@ PROTOTYPES = {
     "goalnet_counter_add": (c_int, [P, c_int64, P]),
     "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, P]),
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
+    "goalnet_adam_step_dev_shadow": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,
+                                             c_int64, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
     "goalnet_frames_preprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),

@@ -109,6 +109,8 @@ class AVM(nn.Module):
         self._arena = self._garena = self._adam_m = self._adam_v = None
         self._hw3 = self._l2 = None
         self._adam_t = 0
+        self._w5b, self._w5b_version = None, None      # bf16 shadow of visbl.linear5.weight and the version stamps it matches
+        self._load_count = 0                           # bumped by load_state_dict (its layout kernels write the arena directly)
         self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
         self._defer_tick = False       # inside train_step: counters advance once, at the end (one launch)
         self._pending_drop_tick = 0
@@ -279,6 +281,7 @@ class AVM(nn.Module):
             raise RuntimeError(f"visbl.linear5.weight has shape {tuple(w5.shape)}, expected (512, 512*H3*W3)")
         hw3 = w5.shape[1] // 512
         l2 = state_dict["audbl.linear3.weight"].shape[1] // 128 if self.audio_included else 0
+        self._load_count += 1
         self._materialize(hw3, l2, init=False)
         expected = set(self._reference_key_order())
         missing = sorted(expected - set(state_dict.keys()))
@@ -336,6 +339,23 @@ class AVM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # forward / backward on device tensors
     # ------------------------------------------------------------------------------------------
+    def _w5_bf16(self, k5):
+        """bf16 copy of visbl.linear5.weight. The fused Adam of train_step refreshes it while it updates the fp32 master
+        (ops.adam_step_dev_shadow), so the next forward needs no 7.7 GB cast pass; any other writer (a stock torch optimizer,
+        load_state_dict, in-place edits of the Parameter or of the arena) changes `_w5_version()` and the copy is re-made."""
+        w5 = self._pflat("visbl.linear5.weight")
+        if self._w5b is None or self._w5b.numel() != w5.numel():
+            self._w5b, self._w5b_version = torch.empty(w5.numel(), dtype=torch.bfloat16, device=self._device), None
+        if self._w5b_version != self._w5_version():
+            ops.cast_bf16(w5, self._w5b)
+            self._w5b_version = self._w5_version()
+        return self._w5b
+
+    def _w5_version(self):
+        """version stamps of everything a Python-side writer of linear5.weight goes through: the arena tensor and the
+        Parameter (whose `.data` alias has its own counter — that is the one a torch optimizer bumps)"""
+        return (self._arena._version, self.visbl.linear5.weight._version, self._load_count)
+
     def _padbuf(self, key, n, h, w, c):
         """Cached zero-padded bf16 activation buffer (borders/guards zeroed once, interior rewritten every step)."""
         k = (key, n, h, w, c)
@@ -440,7 +460,7 @@ class AVM(nn.Module):
         bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
         if bf5:
             xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
-            w5b = ops.cast_bf16(P("visbl.linear5.weight"), torch.empty(512 * k5, dtype=BF16, device=dev))
+            w5b = self._w5_bf16(k5)
             ops.linear_fwd_bf16(xh3.view(n, k5), w5b, P("visbl.linear5.bias"), cat[:, voff:], relu=True,
                                 dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
             if save:
@@ -683,8 +703,14 @@ class AVM(nn.Module):
             self._adam_m = torch.zeros_like(self._arena)
             self._adam_v = torch.zeros_like(self._arena)
         self._adam_t += 1
-        ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
-                          grad_scale, step_bias=1)
+        if self._w5b is not None and self._w5b_version == self._w5_version():
+            # bf16 mode at > 16 rows: refresh the shadow of linear5.weight in the same pass (the kernels do not bump versions)
+            s5 = self.spec("visbl.linear5.weight")
+            ops.adam_step_dev_shadow(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
+                                     self._w5b, s5.offset, grad_scale, step_bias=1)
+        else:
+            ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
+                              grad_scale, step_bias=1)
         if _tick:
             ops.counter_add(self._state[0], 1)
 

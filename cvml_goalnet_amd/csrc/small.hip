@@ -6,6 +6,8 @@
 // kilobytes to a few megabytes: they are written for correctness and determinism, not for a roofline.
 // Adam is the exception: one pass over the flat parameter arena at 28 B/parameter (HBM-bound), it was
 // 57 % of the reference's step at its own sub-batch size.
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 using namespace goalnet;
@@ -318,7 +320,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 // The scalars torch's _single_tensor_adam computes as python floats (doubles) are computed in fp64 here.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t n, double lr, double beta1, double beta2,
-                                                  float eps, const int64_t* __restrict__ step_dev, int64_t step_host, float gs) {
+                                                  float eps, const int64_t* __restrict__ step_dev, int64_t step_host, float gs,
+                                                  uint2* __restrict__ shadow, int64_t sh_b4, int64_t sh_e4) {
     const double t = (double)(step_dev ? *step_dev + step_host : step_host);       // device counter + bias, or the host count
     const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
@@ -336,6 +339,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (shadow && i >= sh_b4 && i < sh_e4) {       // bf16 copy of the updated parameters of one slice (the next step's GEMM operand)
+            const __hip_bfloat16 a = __float2bfloat16(pp.x), b = __float2bfloat16(pp.y), c = __float2bfloat16(pp.z), d = __float2bfloat16(pp.w);
+            shadow[i - sh_b4] = make_uint2((unsigned)*reinterpret_cast<const unsigned short*>(&a) | ((unsigned)*reinterpret_cast<const unsigned short*>(&b) << 16),
+                                           (unsigned)*reinterpret_cast<const unsigned short*>(&c) | ((unsigned)*reinterpret_cast<const unsigned short*>(&d) << 16));
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
@@ -446,14 +454,26 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 }
 
 static int adam_launch(const char* who, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                       double beta2, double eps, const int64_t* step_dev, int64_t step_host, float grad_scale, void* stream) {
+                       double beta2, double eps, const int64_t* step_dev, int64_t step_host, float grad_scale, void* stream,
+                       void* shadow = nullptr, int64_t sh_begin = 0, int64_t sh_count = 0) {
     GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "%s: null pointer", who);
     GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "%s: bad count", who);
     GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "%s: arenas must be 16-byte aligned", who);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
-                       (float)eps, step_dev, step_host, grad_scale);
+                       (float)eps, step_dev, step_host, grad_scale, (uint2*)shadow, sh_begin >> 2, (sh_begin + sh_count) >> 2);
     GN_LAUNCH_CHECK(who);
     return 0;
+}
+
+int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                 double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* shadow_bf16,
+                                 int64_t shadow_begin, int64_t shadow_count, void* stream) {
+    GN_REQUIRE(step && shadow_bf16, GOALNET_E_NULL, "adam_step_dev_shadow: null pointer");
+    GN_REQUIRE(shadow_begin >= 0 && shadow_count > 0 && shadow_begin + shadow_count <= n && (shadow_begin & 3) == 0 && (shadow_count & 3) == 0,
+               GOALNET_E_SHAPE, "adam_step_dev_shadow: the shadowed slice must lie inside the arena, offset and length multiples of 4");
+    GN_REQUIRE((reinterpret_cast<uintptr_t>(shadow_bf16) & 7u) == 0, GOALNET_E_ALIGN, "adam_step_dev_shadow: shadow must be 8-byte aligned");
+    return adam_launch("adam_step_dev_shadow", p, g, m, v, n, lr, beta1, beta2, eps, step, step_bias, grad_scale, stream, shadow_bf16,
+                       shadow_begin, shadow_count);
 }
 
 int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,

@@ -440,6 +440,16 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_
                                       int(step_bias), grad_scale, _s()), "adam_step_dev")
 
 
+def adam_step_dev_shadow(p, g, m, v, lr, beta1, beta2, eps, step, shadow, shadow_begin, grad_scale=1.0, step_bias=0):
+    """adam_step_dev that also writes bf16(p_new) of arena[shadow_begin : shadow_begin + shadow.numel()] into `shadow`"""
+    _chk(p, g, m, v, shadow)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype == torch.bfloat16 and shadow.is_contiguous()
+    check(lib().goalnet_adam_step_dev_shadow(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
+                                             int(step_bias), grad_scale, shadow.data_ptr(), int(shadow_begin), shadow.numel(), _s()),
+          "adam_step_dev_shadow")
+
+
 def rows_copy_batch(segments):
     """segments: up to 4 of (table, block, nrows, cursor, cursor_bias, gather); rows [cursor + bias, +nrows) of `table`
     are read into (gather) or written from (scatter) `block`. One launch."""

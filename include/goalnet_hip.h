@@ -215,6 +215,11 @@ int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, 
 /* goalnet_adam_step with the 1-based step count = *step + step_bias (bias 1: the counter holds the completed steps) */
 int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                           double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* stream);
+/* the same, additionally writing bf16(p_new) for the slice [shadow_begin, shadow_begin + shadow_count) of the arena (both
+ * multiples of 4): the next step's bf16 GEMM operand (visbl.linear5.weight) without a separate 7.7 GB cast pass */
+int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                                 double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale,
+                                 void* shadow_bf16, int64_t shadow_begin, int64_t shadow_count, void* stream);
 /* block[0:nrows] = table[*cursor : *cursor + nrows]  (batch_frames[a:b], main.py:181-184); row_bytes % 4 == 0 */
 int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 /* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */

@@ -386,3 +386,31 @@ def test_bf16_mode_logits_within_1e3_and_gradients_track_the_oracle():
         bad.append(k) if l2 > 0.15 else None
     print(f"[parity] bf16 mode: worst weight-gradient error (of max|g|, device routing): {worst:.2e}")
     assert not bad, f"bf16-mode gradients with relative L2 error > 0.15: {bad}"
+
+
+def test_bf16_weight_shadow_follows_every_writer_of_the_arena():
+    """precision="bf16", > 16 rows: the fused Adam refreshes the bf16 copy of linear5.weight; a stock optimizer step,
+    load_state_dict or an in-place edit must invalidate it (the arena's version counter does)."""
+    n, h = 20, 40
+    aud, vis, lab = inputs(n, h, True)
+    a, b = (load_model(h, True, dropout="off")[0] for _ in range(2))
+    for m in (a, b):
+        m.precision = "bf16"
+    ag, vg, lg = aud.to(DEV), vis.to(DEV), lab.to(DEV)
+    for _ in range(3):
+        a.train_step(ag, vg, lg)                       # a: shadow refreshed by Adam
+        b.train_step(ag, vg, lg)
+        b._w5b_version = None                          # b: forced to re-cast the fp32 master every step
+    torch.cuda.synchronize()
+    assert torch.equal(a._w5b, b._w5_bf16(a._w5b.numel() // 512))
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
+    # an external writer: stock torch Adam on the Parameters
+    opt = torch.optim.Adam(a.parameters(), lr=1e-3)
+    out = a(aud, vis)
+    torch.nn.functional.mse_loss(out[:, 0], lab).backward()
+    before = a._w5b.clone()
+    opt.step()
+    fresh = a._w5_bf16(a._w5b.numel() // 512)
+    assert not torch.equal(before, fresh)
+    assert torch.equal(fresh, a._pflat("visbl.linear5.weight").to(torch.bfloat16))
