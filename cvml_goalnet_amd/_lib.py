@@ -65,7 +65,7 @@ PROTOTYPES = {
     "goalnet_linear_fwd": (c_int, [P, c_int64, P, P, c_int, P, P, c_int, P, c_int64, P, c_int64, P, c_int64,
                                    c_int, c_int64, c_int, P, c_size_t, P]),
     "goalnet_linear_bwd_dx": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
-    "goalnet_linear_bwd_dw": (c_int, [P, c_int64, P, c_int64, P, P, c_int, P, c_int, c_int64, c_int, P]),
+    "goalnet_linear_bwd_dw": (c_int, [P, c_int64, P, c_int64, P, P, c_int, P, P, c_int, c_int64, c_int, P]),
     "goalnet_colsum": (c_int, [P, c_int64, c_int, c_int, P, P]),
     "goalnet_mul": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P]),
     "goalnet_conv1d_fwd": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -539,8 +539,7 @@ class AVM(nn.Module):
         ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
         for key, li in (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
             x_in, m_in = hs[li], ms[li]
-            ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"))
-            ops.colsum(dz, G(f"fusion.{key}.bias"))
+            ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"), db=G(f"fusion.{key}.bias"))
             dprev = torch.empty(n, x_in.shape[1], dtype=F32, device=dev)
             ops.linear_bwd_dx(dz, P(f"fusion.{key}.weight"), dprev, mult=m_in)
             dz = dprev
@@ -551,8 +550,7 @@ class AVM(nn.Module):
             l1, l2, bins = ctx["l1"], ctx["l2"], ctx["bins"]
             dza = dz[:, :128]
             a2f = ctx["a2"].view(n, 128 * l2)
-            ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"))
-            ops.colsum(dza, G("audbl.linear3.bias"))
+            ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"), db=G("audbl.linear3.bias"))
             da2 = torch.empty(n, 128 * l2, dtype=F32, device=dev)
             ops.linear_bwd_dx(dza, P("audbl.linear3.weight"), da2, mult=None)
             ops.relu_bwd(da2, a2f, da2)

@@ -710,7 +710,7 @@ int goalnet_linear_bwd_dx(const float* dy, int64_t lddy, const float* w, const f
 
 int goalnet_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx,
                           const float* scale, const float* shift, int bnC,
-                          float* dw, int M, int64_t K, int J, void* stream) {
+                          float* dw, float* db, int M, int64_t K, int J, void* stream) {
     GN_REQUIRE(dy && x && dw, GOALNET_E_NULL, "linear_bwd_dw: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "linear_bwd_dw: scale/shift must both be set or both NULL");
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dw: bad dims");
@@ -719,7 +719,8 @@ int goalnet_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t
     GN_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw) && aligned16(scale) && aligned16(shift) && lddy % 4 == 0 && ldx % 4 == 0,
                GOALNET_E_ALIGN, "linear_bwd_dw: pointers / leading dims must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (M <= SKINNY_MAX_M) return skinny_linear_dw(dy, lddy, x, ldx, scale, shift, bnC, dw, M, K, J, st);
+    if (M <= SKINNY_MAX_M) return skinny_linear_dw(dy, lddy, x, ldx, scale, shift, bnC, dw, db, M, K, J, st);
+    if (db) { const int rc = goalnet_colsum(dy, lddy, M, J, db, stream); if (rc) return rc; }
     const int ktiles = (M + BK - 1) / BK;
     MCLoader<false>::P ap{dy, lddy, J, M, nullptr, nullptr, 1};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};

@@ -12,6 +12,6 @@ int skinny_linear_fwd(const float* x, int64_t ldx, const float* scale, const flo
 int skinny_linear_dx(const float* dy, int64_t lddy, const float* w, const float* mult, int64_t ldmult, float* dx, int64_t lddx,
                      int M, int64_t K, int J, hipStream_t st);
 int skinny_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* scale, const float* shift, int bnC,
-                     float* dw, int M, int64_t K, int J, hipStream_t st);
+                     float* dw, float* db, int M, int64_t K, int J, hipStream_t st);
 
 }  // namespace goalnet

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
 template <int MR>
 __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                        int64_t ldx, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int bnC, float* __restrict__ dw, int M, int64_t K, int J) {
+                                                       int bnC, float* __restrict__ dw, float* __restrict__ db, int M, int64_t K,
+                                                       int J) {
     constexpr int JR = 32;
     __shared__ __attribute__((aligned(16))) float dys[JR * MR];
     const int tid = threadIdx.x;
@@ -176,6 +177,12 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
     }
     __syncthreads();
     const int jn = J - j0 < JR ? J - j0 : JR;
+    if (db && blockIdx.x == 0 && tid < jn) {            // bias gradient = column sums of dy, rows added in index order
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) t += dys[tid * MR + m];
+        db[j0 + tid] = t;
+    }
     for (int j = 0; j < jn; ++j) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -235,9 +242,9 @@ int skinny_linear_dx(const float* dy, int64_t lddy, const float* w, const float*
 }
 
 int skinny_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* scale, const float* shift, int bnC,
-                     float* dw, int M, int64_t K, int J, hipStream_t st) {
+                     float* dw, float* db, int M, int64_t K, int J, hipStream_t st) {
     const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)((J + 31) / 32));
-    SKINNY_DISPATCH(M, hipLaunchKernelGGL(skinny_dw_kernel<MR>, grid, dim3(256), 0, st, dy, lddy, x, ldx, scale, shift, bnC, dw, M, K, J));
+    SKINNY_DISPATCH(M, hipLaunchKernelGGL(skinny_dw_kernel<MR>, grid, dim3(256), 0, st, dy, lddy, x, ldx, scale, shift, bnC, dw, db, M, K, J));
     GN_LAUNCH_CHECK("linear_bwd_dw(skinny)");
     return 0;
 }

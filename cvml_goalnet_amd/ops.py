@@ -319,12 +319,13 @@ def linear_bwd_dx(dy, w, dx, mult=None):
     return dx
 
 
-def linear_bwd_dw(dy, x, dw, *, scale=None, shift=None, bnC=0):
-    _chk(dy, x, dw, scale, shift)
+def linear_bwd_dw(dy, x, dw, *, scale=None, shift=None, bnC=0, db=None):
+    """db (optional): bias gradient = column sums of dy, produced by the same call"""
+    _chk(dy, x, dw, scale, shift, db)
     M, J = dy.shape
     K = x.shape[1]
-    assert dw.numel() == J * K and x.shape[0] == M
-    check(lib().goalnet_linear_bwd_dw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, dw.data_ptr(),
+    assert dw.numel() == J * K and x.shape[0] == M and (db is None or db.numel() == J)
+    check(lib().goalnet_linear_bwd_dw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, dw.data_ptr(), _p(db),
                                       M, K, J, _s()), "linear_bwd_dw")
     return dw
 

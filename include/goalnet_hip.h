@@ -164,10 +164,10 @@ int goalnet_linear_fwd(const float* x, int64_t ldx, const float* scale, const fl
 /* dx[m][k] = (sum_j dy[m][j] * w[j][k]) * mult[m][k]   (mult nullable) */
 int goalnet_linear_bwd_dx(const float* dy, int64_t lddy, const float* w, const float* mult, int64_t ldmult,
                           float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
-/* dw[j][k] = sum_m dy[m][j] * xa[m][k]   (xa as in goalnet_linear_fwd) */
+/* dw[j][k] = sum_m dy[m][j] * xa[m][k]   (xa as in goalnet_linear_fwd); db[j] = sum_m dy[m][j] when db != NULL */
 int goalnet_linear_bwd_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx,
                           const float* scale, const float* shift, int bnC,
-                          float* dw, int M, int64_t K, int J, void* stream);
+                          float* dw, float* db, int M, int64_t K, int J, void* stream);
 /* out[j] = sum_m x[m][j] (deterministic) — bias gradients */
 int goalnet_colsum(const float* x, int64_t ldx, int M, int J, float* out, void* stream);
 /* y = x * mult (elementwise over [M][J] with leading dims) */

@@ -268,9 +268,11 @@ def test_linear_bwd_dw(m, k, j, affine):
         xd = xd * sc.double()[ch] + sh.double()[ch]
     ref = dy.double().t() @ xd
     dw = torch.full((j, k), float("nan"), device=DEV)
+    db = torch.full((j,), float("nan"), device=DEV)
     ops.linear_bwd_dw(dy.to(DEV), x.to(DEV), dw, scale=None if sc is None else sc.to(DEV), shift=None if sh is None else sh.to(DEV),
-                      bnC=512 if affine else 0)
+                      bnC=512 if affine else 0, db=db)
     close(f"linear_bwd_dw[{m}: {j}x{k}]", dw, ref, rtol=3e-6)
+    close("linear_bwd_dw.db", db, dy.double().sum(0), rtol=1e-6)
     out = torch.empty(j, device=DEV)
     ops.colsum(dy.to(DEV), out)
     close("colsum", out, dy.double().sum(0), rtol=1e-6)
