@@ -33,7 +33,7 @@ import torch.nn as nn
 from torch.nn.parameter import UninitializedParameter
 
 from . import ops
-from ._lib import STAT_PARTS, GoalnetError
+from ._lib import GoalnetError
 from .synth import BASE_SEED, DROP_P, TID_DROP
 
 F32 = torch.float32

@@ -24,12 +24,11 @@ sequence of optimizer steps is exactly the reference's.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 
 from . import ops
-from ._lib import GoalnetError
 
 F32 = torch.float32
 

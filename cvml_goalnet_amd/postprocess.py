@@ -17,7 +17,7 @@ No CPU fallback: without the library / a GPU these functions raise.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 import torch
