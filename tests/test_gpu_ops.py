@@ -420,6 +420,7 @@ def test_to_bf16_padded_layout_exact():
 @pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [
     (2, 7, 5, 64, 256, True, True), (3, 13, 13, 64, 256, True, True), (16, 11, 11, 256, 512, True, True),
     (16, 11, 11, 512, 256, False, False), (2, 13, 13, 256, 64, False, False), (9, 40, 36, 64, 320, True, True),
+    (1, 7, 5, 64, 256, True, True), (3, 7, 7, 64, 260, False, False),      # 35 / 147 pixels: the last quad of rows is only partly valid
 ])
 def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu, tile, monkeypatch):
     monkeypatch.setenv("GOALNET_BF16_TILE", tile)         # read by the entry point at call time; unset = chosen by size
