@@ -267,6 +267,38 @@ __device__ __forceinline__ void store_acc_h(const EpiP& ep, const f32x16 (&acc)[
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
     const int r = lane & 31, h = lane >> 5;
+    // 16-byte stores after an in-quad transpose (gemm_common.h: quad_transpose4) for the modes whose epilogue is a function of
+    // (value, column) [+ one multiplier per element]; needs 16-byte aligned rows. EPI_FULL keeps the element-wise form.
+    const bool wide = mode != EPI_FULL && (ep.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(outp) & 15u) == 0 &&
+                      (mode != EPI_MUL || ((ep.ldmul & 3) == 0 && (reinterpret_cast<uintptr_t>(ep.mul) & 15u) == 0));
+    if (wide) {
+        const int r4 = r & ~3;
+        const float lo = (mode == EPI_BIAS_RELU && ep.relu) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) {
+                const int col = tn * BN + frag_index<BTR>(wn, fn, r4);               // first of 4 consecutive columns
+                const bool colok = col < ep.cols;                                    // cols % 4 == 0 at every call site
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mode == EPI_BIAS_RELU && ep.bias && colok) bv = *reinterpret_cast<const float4*>(ep.bias + col);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float n0 = acc[fm][fn][4 * g], n1 = acc[fm][fn][4 * g + 1], n2 = acc[fm][fn][4 * g + 2], n3 = acc[fm][fn][4 * g + 3];
+                    quad_transpose4(n0, n1, n2, n3, lane);
+                    const int64_t row = (int64_t)tm * BM + frag_index<ATR>(wm, fm, (lane & 3) + 8 * g + 4 * h);
+                    if (!(colok && row < ep.rows)) continue;
+                    float4 v = make_float4(n0, n1, n2, n3);
+                    if (mode == EPI_BIAS_RELU) v = make_float4(fmaxf(n0 + bv.x, lo), fmaxf(n1 + bv.y, lo), fmaxf(n2 + bv.z, lo), fmaxf(n3 + bv.w, lo));
+                    else if (mode == EPI_MUL) {
+                        const float4 mv = *reinterpret_cast<const float4*>(ep.mul + row * ep.ldmul + col);
+                        v = make_float4(n0 * mv.x, n1 * mv.y, n2 * mv.z, n3 * mv.w);
+                    }
+                    *reinterpret_cast<float4*>(outp + row * ep.ld + col) = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll

@@ -330,12 +330,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));                    // no DMA may land after the block has released its LDS
 
     // epilogue (conv forward: bias + ReLU; data gradient: raw; weight gradient / linear5 forward: raw split-K slab).
-    // A lane of the 32x32 accumulator holds 4 consecutive ROWS of one column per register group; a 4 x 4 transpose inside each
-    // quad of lanes (two DPP stages: swap bit 0, then bit 1, of register index against lane index) turns that into 4 consecutive
-    // COLUMNS of one row, i.e. one 16-byte store per lane and whole 128-B lines per quad row: 32 store instructions per wave
-    // instead of 128 (the tail of a 256 x 256 fp32 tile is store-issue-bound when K is short, e.g. linear5 dX).
+    // A lane of the 32x32 accumulator holds 4 consecutive ROWS of one column per register group; quad_transpose4
+    // (gemm_common.h) turns that into 4 consecutive COLUMNS of one row, i.e. one 16-byte store per lane and whole 128-B lines
+    // per quad row: 32 store instructions per wave instead of 128 (the tail of a 256 x 256 fp32 tile is store-issue-bound).
     const int r = lane & 31, hh = lane >> 5;
-    const bool l0 = lane & 1, l1 = lane & 2;
     const bool brelu = ep.mode == EPI_BIAS_RELU && ep.slab_stride == 0;
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
@@ -350,28 +348,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
             if (brelu && ep.bias && colok) bv = *reinterpret_cast<const float4*>(ep.bias + col);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float m0 = acc[mi][ni][4 * g], m1 = acc[mi][ni][4 * g + 1], m2 = acc[mi][ni][4 * g + 2], m3 = acc[mi][ni][4 * g + 3];
-                // The cross-lane moves are volatile asm: they must execute with all lanes active, before any predicate. (As
-                // builtins inside `?:` the compiler turned the selects into exec-masked regions and the moves then read disabled
-                // lanes: only the diagonal of each 4 x 4 block survived.)
-                float x0, x1, x2, x3;
-                asm volatile("s_nop 1\n\t"
-                             "v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(m0), "v"(m1), "v"(m2), "v"(m3));
-                // stage A: A[k](l1,l0) = M[2 k1 + l0](l1, k0)
-                const float a0 = l0 ? x1 : m0, a1 = l0 ? m1 : x0, a2 = l0 ? x3 : m2, a3 = l0 ? m3 : x2;
-                float y0, y1, y2, y3;
-                asm volatile("s_nop 1\n\t"        /* gfx9 hazard: a VALU write of a DPP source needs 2 wait states before the DPP reads it */
-                             "v_mov_b32_dpp %0, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %2, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                             "v_mov_b32_dpp %3, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                             : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-                // stage B: N[j](l1,l0) = A[2 l1 + j0](j1, l0)
-                const float n0 = l1 ? y2 : a0, n1 = l1 ? y3 : a1, n2 = l1 ? a2 : y0, n3 = l1 ? a3 : y1;
+                float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
+                quad_transpose4(n0, n1, n2, n3, lane);
                 const int i = (lane & 3) + 8 * g + 4 * hh;
                 const int64_t row = (int64_t)tm * T + (TRA ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (i & 15) + 64 * (i >> 4)
                                                            : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + i);

@@ -87,6 +87,31 @@ __device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2]
         }
 }
 
+// 4 x 4 transpose inside each quad of lanes: on entry register k of lane l holds element (row k, column l) of the quad's
+// block, on exit register j of lane l holds (row l, column j). Two stages (swap bit 0, then bit 1, of register index against
+// lane index). The cross-lane moves are volatile asm so that they run with all lanes active, ahead of any predicate: as
+// builtins inside `?:` the compiler turned the selects into exec-masked regions and the moves read disabled lanes. The s_nop
+// covers the gfx9 hazard "VALU write of a DPP source needs 2 wait states before the DPP reads it".
+__device__ __forceinline__ void quad_transpose4(float& m0, float& m1, float& m2, float& m3, int lane) {
+    const bool l0 = lane & 1, l1 = lane & 2;
+    float x0, x1, x2, x3;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+    const float a0 = l0 ? x1 : m0, a1 = l0 ? m1 : x0, a2 = l0 ? x3 : m2, a3 = l0 ? m3 : x2;      // A[k](l1,l0) = M[2 k1 + l0](l1, k0)
+    float y0, y1, y2, y3;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %3, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    m0 = l1 ? y2 : a0; m1 = l1 ? y3 : a1; m2 = l1 ? a2 : y0; m3 = l1 ? a3 : y1;                    // N[j](l1,l0) = A[2 l1 + j0](j1, l0)
+}
+
 __device__ __forceinline__ void tile_of_block(int tiles_m, int tiles_n, int m_fast, int& tm, int& tn) {
     const unsigned v = xcd_remap(blockIdx.x, (unsigned)(tiles_m * tiles_n));
     if (m_fast) { tm = (int)(v % (unsigned)tiles_m); tn = (int)(v / (unsigned)tiles_m); }
