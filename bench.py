@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true")
     ap.add_argument("--no-native40", action="store_true", help="skip the extra 40x40 / 10-frame loop measurement")
+    ap.add_argument("--global-batch", action="store_true",
+                    help="N > 1: BatchNorm statistics and the broadcast MSE over all ranks' frames, gradients summed "
+                         "(ddp.SyncStats: the step equals one reference process on the global batch)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "bf16"),
                     help="bf16 (default) = bf16-MFMA contractions with fp32 accumulation/statistics/master weights, logits within "
                          "the north star's 1e-3 of the fp32 CPU reference; f32 = the reference's arithmetic on the fp32 matrix cores")
@@ -249,7 +252,10 @@ def main():
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if args.no_audio:
         aud = None
-    if distributed:
+    if distributed and args.global_batch:
+        from cvml_goalnet_amd.ddp import enable_global_batch
+        enable_global_batch(model, compress="bf16" if args.dtype == "bf16" else None)
+    elif distributed:
         model.grad_sync = GradSync(compress="bf16" if args.dtype == "bf16" else None)
 
     parity = None
@@ -291,7 +297,9 @@ def main():
             "config": {"workload": f"AVM train step (forward + broadcast-MSE + backward + fused Adam), {args.clips} clips x 16 frames = "
                                    f"{n} frames of 3x{h}x{w} + 30x30 MFCC per GPU; dropout live (device masks), BatchNorm train mode",
                        "frames_per_gpu": n, "h": h, "w": w, "global_clips_per_step": args.clips * world,
-                       "parallelism": f"dp{world}", "ddp_semantics": "local BN + local MSE per rank, gradient mean (standard DDP)" +
+                       "parallelism": f"dp{world}", "ddp_semantics": ("BatchNorm sums + broadcast MSE over all ranks' frames, gradient sum (global batch)"
+                                                                 if distributed and args.global_batch else
+                                                                 "local BN + local MSE per rank, gradient mean (standard DDP)") +
                        ("; linear5.weight gradient exchanged as bf16" if args.dtype == "bf16" and distributed else ""),
                        "params": int(sum(s.numel for s in model._specs)), "final_loss": float(loss.item())},
         }

@@ -116,6 +116,7 @@ class AVM(nn.Module):
         self._pending_drop_tick = 0
         self._materialized = False
         self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
+        self.stat_sync = None          # optional ddp.SyncStats: BatchNorm sums and the loss over all ranks' frames
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
@@ -383,6 +384,12 @@ class AVM(nn.Module):
         h1, w1 = (h + 3) // 3 + 1, (w + 3) // 3 + 1
         return (h1, w1), (h1 - 2, w1 - 2), (h1 - 4, w1 - 4), (h1 - 6, w1 - 6)
 
+    def _global_sums(self, partials, width):
+        """ddp.SyncStats: this rank's partial rows -> one row of `width` doubles -> all-reduce(SUM) over the ranks"""
+        row = torch.empty(width, dtype=torch.float64, device=self._device)
+        ops.partials_sum_f64(partials, width, row)
+        return self.stat_sync.all_reduce(row)
+
     def _bn_block(self, y, n, hc, wc, c, i, save):
         """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift)."""
         dev = self._device
@@ -393,8 +400,11 @@ class AVM(nn.Module):
         ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
         bn = getattr(self.visbl, f"bnorm{i}")
         st = torch.empty(4, c, dtype=F32, device=dev)
+        count = n * (hc - 2) * (wc - 2)
+        if self.stat_sync is not None:
+            partials, count = self._global_sums(partials, 2 * c), count * self.stat_sync.world
         ops.bn_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
-                        bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, n * (hc - 2) * (wc - 2), c,
+                        bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, count, c,
                         st[0], st[1], st[2], st[3])
         bn.num_batches_tracked += 1
         return p, idx, st
@@ -513,6 +523,12 @@ class AVM(nn.Module):
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
                             G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
+        if self.stat_sync is not None:
+            # dgamma / dbeta above are this rank's sums (the gradient all-reduce adds the ranks up); the dx coefficients
+            # need the sums over every rank's pixels
+            scratch = torch.empty(2 * c, dtype=F32, device=dev)
+            ops.bn_bwd_finalize(self._global_sums(partials, 2 * c), self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1],
+                                npix * self.stat_sync.world, c, scratch[:c], scratch[c:], coef3)
         dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)        # dbias partials per (frame, row band)
         if self.precision == "bf16" and i > 1:
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
@@ -683,7 +699,14 @@ class AVM(nn.Module):
         n = out.numel()
         loss = torch.empty(1, dtype=F32, device=self._device)
         dout = torch.empty(n, dtype=F32, device=self._device)
-        ops.mse_bcast(out, labels, loss, dout)
+        if self.stat_sync is not None:
+            # the (N, N) broadcast couples every prediction with every label of the batch: evaluate it on the rank-ordered
+            # concatenation and keep this rank's slice of dL/dp
+            gout = torch.empty(n * self.stat_sync.world, dtype=F32, device=self._device)
+            ops.mse_bcast(self.stat_sync.gather(out), self.stat_sync.gather(labels.to(F32)), loss, gout)
+            dout = gout[n * self.stat_sync.rank: n * (self.stat_sync.rank + 1)]
+        else:
+            ops.mse_bcast(out, labels, loss, dout)
         sync = self.grad_sync
         self.last_ctx = ctx if self.keep_ctx else None
         self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)

@@ -449,6 +449,14 @@ __global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restr
     if (c < C && threadIdx.x < 16) out[c] = (float)s;
 }
 
+__global__ __launch_bounds__(256) void partials_sum_f64_kernel(const double* __restrict__ partials, int nparts, int64_t stride,
+                                                              int C, double* __restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = column_sum16(partials + c, nparts, stride, c < C, sm);
+    if (c < C && threadIdx.x < 16) out[c] = s;
+}
+
 // partial rows beyond one per frame are spent on row bands inside each frame (>= 3 rows per band)
 int row_bands(int nparts, int N, int rows) {
     int b = nparts / N;
@@ -563,6 +571,14 @@ int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int
     GN_REQUIRE(nparts > 0 && C > 0 && stride >= C, GOALNET_E_SHAPE, "partials_sum: bad dims");
     hipLaunchKernelGGL(partials_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
     GN_LAUNCH_CHECK("partials_sum");
+    return 0;
+}
+
+int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream) {
+    GN_REQUIRE(partials && out, GOALNET_E_NULL, "partials_sum_f64: null pointer");
+    GN_REQUIRE(nparts > 0 && C > 0 && stride >= C, GOALNET_E_SHAPE, "partials_sum_f64: bad dims");
+    hipLaunchKernelGGL(partials_sum_f64_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
+    GN_LAUNCH_CHECK("partials_sum_f64");
     return 0;
 }
 

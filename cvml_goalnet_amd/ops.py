@@ -165,6 +165,13 @@ def partials_sum(partials, nparts, stride, C, out):
     check(lib().goalnet_partials_sum(partials.data_ptr(), nparts, stride, C, out.data_ptr(), _s()), "partials_sum")
 
 
+def partials_sum_f64(partials, C, out):
+    """out[c] (double) = sum over the rows of partials[rows][C]"""
+    _chk(partials, out)
+    assert partials.dtype == torch.float64 and out.dtype == torch.float64 and out.numel() == C
+    check(lib().goalnet_partials_sum_f64(partials.data_ptr(), _rows(partials, C), C, C, out.data_ptr(), _s()), "partials_sum_f64")
+
+
 def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(x, scale, shift, w, bias, y)
     assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin

@@ -98,6 +98,9 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
                              void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
+/* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
+ * (ddp.SyncStats; SURVEY.md §8(e) "SyncBN": all-reduce of per-channel sum(x), sum(x^2)) */
+int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream);
 
 /* ---- VisBl blocks 2,3: conv 3x3 s1 p1 as implicit GEMM on fp32 MFMA.  utils.py:156-157, 161-162 --- */
 /* y = [relu](conv(bnapply(x), w) + bias).  scale/shift (per input channel) may be NULL (no BN on load);

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cvml_goalnet_amd import AVM, synth
-from cvml_goalnet_amd.ddp import GradSync, bucket_slices
+from cvml_goalnet_amd.ddp import GradSync, SyncStats, bucket_slices
 
 
 def test_synth_is_counter_based_and_stable():
@@ -104,3 +104,29 @@ def test_gradient_exchange_world2_gloo(tmp_path):
     assert torch.allclose(r0["reduced"], mean, rtol=0, atol=1e-12 + 1e-6 * mean.abs().max().item())
     assert torch.equal(r0["reduced"], r1["reduced"])
     assert not torch.equal(r0["local"], r1["local"])
+
+
+def _syncstats_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = SyncStats()
+    row = torch.arange(6, dtype=torch.float64) * (rank + 1) + 2.0 ** -40          # bits a float32 exchange would drop
+    got = {"rank": st.rank, "world": st.world, "sum": st.all_reduce(row.clone()),
+           "cat": st.gather(torch.arange(3, dtype=torch.float32) + 10 * rank), "avg": GradSync(average=False).finish(None)}
+    torch.save(got, os.path.join(tmp, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_syncstats_collectives_world2_gloo(tmp_path):
+    """global-batch mode's host side: per-channel sums are added in double, predictions / labels are concatenated in
+    rank order, and the summed gradient is not divided by the world size (SyncBN)."""
+    import torch.multiprocessing as mp
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_syncstats_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = torch.load(tmp_path / f"s{rank}.pt")
+        assert (got["rank"], got["world"], got["avg"]) == (rank, 2, 1.0)
+        assert torch.equal(got["sum"], torch.arange(6, dtype=torch.float64) * 3 + 2.0 ** -39)
+        assert got["cat"].tolist() == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
