@@ -11,7 +11,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgoalnet_hip.so")
+LIB_PATH = os.environ.get("GOALNET_LIB_PATH") or os.path.join(_HERE, "libgoalnet_hip.so")   # override: A/B builds of the kernels
 ABI_VERSION = 1
 STAT_PARTS = 1024
 
