@@ -145,6 +145,31 @@ __device__ __forceinline__ bf16x8 read_frag_tr(const char* half, int u, int ks, 
     return bf16x8{v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
 }
 
+// The same fragment through inline asm, for the phased loop below. hipcc cannot tell what a `ds_read_tr` builtin may alias
+// and puts `s_waitcnt vmcnt(0)` in front of every group of them while LDS-DMA is in flight — a full drain of the staging
+// pipeline in every phase (ISA of the weight-gradient kernel: 30 drains per two K-tiles). As asm the reads carry no such
+// wait; what the compiler no longer provides is done by hand: `s_waitcnt lgkmcnt(0)` before the phase's MFMAs (GN_PHASE),
+// all statements volatile (issued in source order). Per-lane byte address of fragment u, read t (t = 0, 1: k rows 4t + q
+// of each group of 8), K-step and slot as immediates; the K-tile parity (64 KB apart) is flipped INTO the address registers
+// so that every immediate stays below 64 KB.
+__device__ __forceinline__ unsigned tr_lane_addr(unsigned lds0, int u, int t, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int chunk = 2 * (u + 4 * (g & 1)) + (p >> 1);
+    const int kr = 8 * (g >> 1) + 4 * t + q;
+    return lds0 + (unsigned)(kr * TROWB + tr_chunk(kr, chunk) * 16 + (p & 1) * 8);
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 rd_tr(const unsigned (&ad)[2]) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    s16x4 v0, v1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v0) : "v"(ad[0]), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v1) : "v"(ad[1]), "n"(OFF) : "memory");
+    return bf16x8{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+}
+#define GN_RD_TR4(DST, AD, S)                                                                               \
+    DST[0] = rd_tr<(S) * HALF_BYTES + 0 * 16 * TROWB>(AD); DST[1] = rd_tr<(S) * HALF_BYTES + 1 * 16 * TROWB>(AD);  \
+    DST[2] = rd_tr<(S) * HALF_BYTES + 2 * 16 * TROWB>(AD); DST[3] = rd_tr<(S) * HALF_BYTES + 3 * 16 * TROWB>(AD);
+
 // plain matrix X[kred][cols] (dy_pad [pixels][Cout]): re-based every K-tile; rows past kred / columns past `cols` read 0
 struct MCLoader256 {
     struct P { const __hip_bfloat16* x; int64_t ld; int cols; int64_t kred; };
@@ -228,6 +253,7 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 #define GN_PHASE(ACC0, ACC1, AF, BF)                                                                        \
+    if constexpr (TRA || TRB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* the asm fragment reads (rd_tr) */ \
     asm volatile("s_barrier\n\ts_setprio 1" ::: "memory");                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
         mfma_pinned(ACC0, AF[0][ks], BF[ks]);                                                               \
@@ -282,35 +308,48 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // fragments of the NEXT K-tile are read in phase q3 into the registers B1 has just left, so every phase issues at most
     // 8 ds_read_b128 per wave (8 | 4 | 8 | 4) and the LDS time of a phase stays within one MFMA section.
     bf16x8 a[2][4], bx[4], by[4];
-    auto rdA = [&](const char* half, int f, int ks) -> bf16x8 {
-        return TRA ? read_frag_tr(half, 2 * wr + f, ks, lane) : read_frag(half, wr * 64 + f * 32, ks, lane);
-    };
-    auto rdB = [&](const char* half, int ks) -> bf16x8 {
-        return TRB ? read_frag_tr(half, wc, ks, lane) : read_frag(half, wc * 32, ks, lane);
-    };
+    // fragment reads: K-contiguous operands by pointer (compiler-scheduled ds_read_b128), row-contiguous ones by rd_tr
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned adA[2][2], adB[2];                      // [f][t], [t]: K-tile parity folded in (GN_FLIP)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bx[ks] = rdB(slot(0, 2), ks);
+    for (int t = 0; t < 2; ++t) {
+        adA[0][t] = tr_lane_addr(lds0, 2 * wr, t, lane); adA[1][t] = tr_lane_addr(lds0, 2 * wr + 1, t, lane);
+        adB[t] = tr_lane_addr(lds0, wc, t, lane);
+    }
+#define GN_FLIP_A() { adA[0][0] ^= 4u * HALF_BYTES; adA[0][1] ^= 4u * HALF_BYTES; adA[1][0] ^= 4u * HALF_BYTES; adA[1][1] ^= 4u * HALF_BYTES; }
+#define GN_FLIP_B() { adB[0] ^= 4u * HALF_BYTES; adB[1] ^= 4u * HALF_BYTES; }
+    // S = slot of the half inside its K-tile (0 A0, 1 A1, 2 B0, 3 B1); TT = the K-tile (pointer form only)
+#define GN_RD_A(TT, S)                                                                                      \
+    if constexpr (TRA) { GN_RD_TR4(a[0], adA[0], S) GN_RD_TR4(a[1], adA[1], S) }                            \
+    else {                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = read_frag(slot(TT, S), wr * 64 + f * 32, ks, lane); \
+    }
+#define GN_RD_B(DST, TT, S)                                                                                 \
+    if constexpr (TRB) { GN_RD_TR4(DST, adB, S) }                                                           \
+    else { _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = read_frag(slot(TT, S), wc * 32, ks, lane); }
+    GN_RD_B(bx, 0, 2)
 
 #define GN_KTILE(TT, B0R, B1R)                                                                              \
     {                                                                                                       \
         const int t_ = (TT);                                                                                \
         /* q0: (A0, B0) */                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = rdA(slot(t_, 0), f, ks); \
+        GN_RD_A(t_, 0)                                                                                      \
         al.issue(kt0 + t_ + 1, 1, slot(t_ + 1, 1));                                                               \
         GN_PHASE(acc[0][0], acc[1][0], a, B0R);                                                             \
         /* q1: (A0, B1) */                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = rdB(slot(t_, 3), ks);  \
+        GN_RD_B(B1R, t_, 3)                                                                                 \
         bl.issue(kt0 + t_ + 2, 0, slot(t_, 2));                                                                   \
         GN_PHASE(acc[0][1], acc[1][1], a, B1R);                                                             \
         /* q2: (A1, B1); B0 of the next K-tile must have landed one phase before q3 reads it */             \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f) a[f][ks] = rdA(slot(t_, 1), f, ks); \
+        GN_RD_A(t_, 1)                                                                                      \
+        if constexpr (TRA) GN_FLIP_A()                                                                      \
         al.issue(kt0 + t_ + 2, 0, slot(t_, 0));                                                                   \
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                    \
         GN_PHASE(acc[2][1], acc[3][1], a, B1R);                                                             \
         /* q3: (A1, B0); the counted wait that retires K-tile t+1 */                                        \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) B1R[ks] = rdB(slot(t_ + 1, 2), ks); \
+        if constexpr (TRB) GN_FLIP_B()                                                                      \
+        GN_RD_B(B1R, t_ + 1, 2)                                                                             \
         bl.issue(kt0 + t_ + 2, 1, slot(t_, 3));                                                                   \
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                    \
         GN_PHASE(acc[2][0], acc[3][0], a, B0R);                                                             \
