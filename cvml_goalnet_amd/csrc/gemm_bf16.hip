@@ -747,6 +747,13 @@ int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: bad dims");
     GN_REQUIRE(J % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: J, K, lds %% 8");
     GN_REQUIRE(aligned16(dy_bf16) && aligned16(x_bf16) && aligned16(dw), GOALNET_E_ALIGN, "linear_bwd_dw_bf16: alignment");
+    {
+        // >= 256 output rows, a reduction of at least 4 K-tiles and an output wide enough to fill the chip with 256^2 tiles
+        const char* forced = getenv("GOALNET_BF16_TILE");
+        const bool big = forced ? forced[0] == '2' : (J >= 256 && M >= 256 && K >= (1 << 18));
+        if (big) return launch_linear_dw_bf16_256("linear_bwd_dw_bf16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)x_bf16,
+                                                  ldx, M, K, J, dw, (hipStream_t)stream);
+    }
     MCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, J, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)x_bf16, ldx, (int)K, M};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};

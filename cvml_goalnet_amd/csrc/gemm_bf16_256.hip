@@ -506,6 +506,30 @@ int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_
     return 0;
 }
 
+// dw[J][K] (fp32) = dy[M][J]^T . x[M][K]: both operands row-contiguous (the reduction index m is the slow one), no split:
+// a short reduction (M / 64 K-tiles) into a huge output — the 256^2 tile quarters the operand traffic per output byte
+int launch_linear_dw_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* x, int64_t ldx, int M,
+                              int64_t K, int J, float* dw, hipStream_t st) {
+    typedef MCLoader256 AL;
+    typedef MCLoader256 BL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int64_t tiles_m = (J + T - 1) / T, tiles_n = (K + T - 1) / T;
+    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
+    const int ktiles = (M + BKH - 1) / BKH;
+    AL::P ap{dy, lddy, J, M};
+    BL::P bp{x, ldx, (int)K, M};
+    EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 5>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
+                       (int)tiles_m, (int)tiles_n, 1, ktiles, ktiles);
+    GN_LAUNCH_CHECK(name);
+    return 0;
+}
+
 // conv 3x3 weight gradient on the zero-padded pixel grid: slabs[split][Cout][9*Cin] (fp32), reduced by the caller
 int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
                           int64_t Mp, float* slabs, int nsplit, hipStream_t st) {

@@ -38,6 +38,8 @@ int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_
                                int J, float* slabs, int nsplit, hipStream_t st);
 int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
                               int J, float* dx, int64_t lddx, hipStream_t st);
+int launch_linear_dw_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* x, int64_t ldx, int M,
+                              int64_t K, int J, float* dw, hipStream_t st);
 int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
                           int64_t Mp, float* slabs, int nsplit, hipStream_t st);
 

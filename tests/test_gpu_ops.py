@@ -503,3 +503,18 @@ def test_phased_256_kernels_at_the_sizes_that_select_them(monkeypatch):
         err = (a - r).abs().max().item()
         print(f"[parity] conv3 {name}: 256-tile vs 128-tile max |diff| {err:.3e} (max |ref| {scale:.3e})")
         assert err <= 2e-5 * scale, name
+    # linear weight gradient: J >= 256, M >= 256 frames, K >= 2^18 select the 256 tile (both operands row-contiguous)
+    m, j, k = 320, 512, (1 << 18) + 264                                 # ragged in M (5 K-tiles) and K (partial last tile)
+    dyl = (torch.rand(m, j, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    xl = (torch.rand(m, k, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    res = {}
+    for tile in ("auto", "128"):
+        if tile == "auto":
+            monkeypatch.delenv("GOALNET_BF16_TILE", raising=False)
+        else:
+            monkeypatch.setenv("GOALNET_BF16_TILE", tile)
+        res[tile] = ops.linear_bwd_dw_bf16(dyl, xl, torch.empty(j, k, device=DEV))
+    ref = dyl[:, :8].double().t() @ xl.double()                         # exact products of bf16 values: 8 rows in fp64
+    scale = ref.abs().max().item()
+    assert (res["auto"][:8].double() - ref).abs().max().item() <= 3e-6 * scale
+    assert (res["auto"] - res["128"]).abs().max().item() <= 2e-5 * scale, "linear weight gradient"
