@@ -117,6 +117,7 @@ class AVM(nn.Module):
         self._materialized = False
         self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
         self.stat_sync = None          # optional ddp.SyncStats: BatchNorm sums and the loss over all ranks' frames
+        self.grad_bf16 = os.environ.get("GOALNET_DZ16", "1") != "0"   # precision="bf16": bf16 BatchNorm-output gradients (backward_device)
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
@@ -583,7 +584,12 @@ class AVM(nn.Module):
         p3f = ctx["p3"].view(n, k5)
         st3 = ctx["st3"]
         bf = self.precision == "bf16"
-        dbn3 = torch.empty(n, hp3, wp3, 512, dtype=F32, device=dev)
+        # precision="bf16": where the 256 x 256 tile serves the data-gradient GEMM, the gradient wrt a BatchNorm output is
+        # stored as bf16 (fp32 accumulators rounded once, at the store): its only readers are the two HBM-bound passes of
+        # _block_bwd, and the GEMMs behind them consume bf16 anyway
+        dz16 = bf and self.grad_bf16
+        o16_3 = dz16 and ctx["bf5"] and ops.linear_bwd_dx_bf16_o16_ok(n, k5, 512)
+        dbn3 = torch.empty(n, hp3, wp3, 512, dtype=torch.bfloat16 if o16_3 else F32, device=dev)
         if bf and ctx["padgen"] != (self._padgen["x1"], self._padgen["x2"]):
             raise RuntimeError("precision='bf16': a second training-mode forward overwrote the saved bf16 operands before "
                                "backward ran; call backward after each forward (as the reference's loop does)")
@@ -592,7 +598,10 @@ class AVM(nn.Module):
             ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight"))
             if on_bucket:
                 on_bucket(1)
-            ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
+            if o16_3:
+                ops.linear_bwd_dx_bf16_o16(dz5b, ctx["w5b"], dbn3.view(n, k5))
+            else:
+                ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
         else:
             ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512)
             if on_bucket:
@@ -612,11 +621,16 @@ class AVM(nn.Module):
                         ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
-        dbn2 = torch.empty(n, hp2, wp2, 256, dtype=F32, device=dev)
+        o16_2 = dz16 and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
+        dbn2 = torch.empty(n, hp2, wp2, 256, dtype=torch.bfloat16 if o16_2 else F32, device=dev)
         if self.precision == "bf16":
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
-            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
-                        dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
+            if o16_2:
+                self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p_o16,
+                            dyp3, wtb, dbn2, n, hp2, wp2, 512, 256)
+            else:
+                self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
+                            dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
         else:
             self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
                         dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)

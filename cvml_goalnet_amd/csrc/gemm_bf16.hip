@@ -628,6 +628,12 @@ static int conv_splits_h(int64_t M, int Cin, int Cout) {
     return conv_fwd_splits(((M + BM - 1) / BM) * ((Cout + BN - 1) / BN), 9 * Cin / BKH);
 }
 
+// large problems: the 256 x 256 phased tile (gemm_bf16_256.hip); GOALNET_BF16_TILE=128 / 256 forces a choice (tests, A/B runs)
+static bool conv_use_256(int64_t M, int Cout) {
+    const char* forced = getenv("GOALNET_BF16_TILE");
+    return forced ? forced[0] == '2' : (Cout >= 256 && M >= 65536);
+}
+
 size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
     const int64_t M = (int64_t)N * H * W;
@@ -650,9 +656,7 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
     EpiP ep = efinal;
     // large problems: the 256 x 256 phased tile (gemm_bf16_256.hip); GOALNET_BF16_TILE=128 / 256 forces a choice (tests, A/B runs)
     {
-        const char* forced = getenv("GOALNET_BF16_TILE");
-        const bool big = forced ? forced[0] == '2' : (Cout >= 256 && M >= 65536);
-        if (big) return launch_conv_bf16_256("conv3x3_fwd_bf16p(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M,
+        if (conv_use_256(M, Cout)) return launch_conv_bf16_256("conv3x3_fwd_bf16p(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M,
                                              (const __hip_bfloat16*)w_bf16, Cout, efinal, st);
     }
     const int nsplit = ws ? conv_splits_h(M, Cin, Cout) : 1;
@@ -664,6 +668,29 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
     const int rc = launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, st);
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("conv3x3_fwd_bf16p.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
+}
+
+/* 1 when goalnet_conv3x3_fwd_bf16p_o16 serves these dims (the shapes the 256 x 256 tile takes), else 0 */
+int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BKH != 0 || Cout % 8 != 0) return 0;
+    return conv_use_256((int64_t)N * H * W, Cout) ? 1 : 0;
+}
+
+/* y_bf16[N][H][W][Cout] = bf16(conv3x3(x_pad, w)): no bias, no ReLU — the data-gradient use (w = flipped weights); the
+ * fp32 accumulator is rounded once, at the store */
+int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, void* y_bf16, int N, int H, int W, int Cin, int Cout,
+                                  void* stream) {
+    GN_REQUIRE(x_pad && w_bf16 && y_bf16, GOALNET_E_NULL, "conv3x3_fwd_bf16p_o16: null pointer");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: non-positive dim");
+    GN_REQUIRE(Cin % BKH == 0 && Cout % 8 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: Cin %% 64, Cout %% 8");
+    GN_REQUIRE(aligned16(x_pad) && aligned16(w_bf16) && aligned16(y_bf16), GOALNET_E_ALIGN, "conv3x3_fwd_bf16p_o16: alignment");
+    const int64_t M = (int64_t)N * H * W;
+    GN_REQUIRE((int64_t)N * (H + 2) * (W + 2) < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: too many pixels");
+    GN_REQUIRE(goalnet_conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout), GOALNET_E_SHAPE,
+               "conv3x3_fwd_bf16p_o16: dims not served (ask goalnet_conv3x3_fwd_bf16p_o16_ok; use goalnet_conv3x3_fwd_bf16p)");
+    const EpiP ep{EPI_BIAS_RELU, nullptr, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, 0, y_bf16};
+    return launch_conv_bf16_256("conv3x3_fwd_bf16p_o16(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M, (const __hip_bfloat16*)w_bf16,
+                                Cout, ep, (hipStream_t)stream);
 }
 
 static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {
@@ -733,11 +760,29 @@ int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_
     GN_REQUIRE(aligned16(dy_bf16) && aligned16(w_bf16) && aligned16(dx), GOALNET_E_ALIGN, "linear_bwd_dx_bf16: alignment");
     if (!mult && linear_use_256(M, K, J))
         return launch_linear_dx_bf16_256("linear_bwd_dx_bf16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)w_bf16, M, K,
-                                         J, dx, lddx, (hipStream_t)stream);
+                                         J, dx, nullptr, lddx, (hipStream_t)stream);
     KCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, K, (int)K, J};
     EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};
     return launch_gemm_h<KCLoaderH, MCLoaderH>("linear_bwd_dx_bf16", ap, bp, ep, M, K, J / BKH, 1, 1, (hipStream_t)stream);
+}
+
+/* 1 when goalnet_linear_bwd_dx_bf16_o16 serves these dims (the shapes the 256 x 256 tile takes), else 0 */
+int goalnet_linear_bwd_dx_bf16_o16_ok(int M, int64_t K, int J) {
+    return M > 0 && J > 0 && K > 0 && J % BKH == 0 && K % 8 == 0 && linear_use_256(M, K, J) ? 1 : 0;
+}
+
+/* dx_bf16[m][k] = bf16(sum_j dy_bf16[m][j] * w_bf16[j][k]): the data gradient rounded once, at the store (fp32 accumulation) */
+int goalnet_linear_bwd_dx_bf16_o16(const void* dy_bf16, int64_t lddy, const void* w_bf16, void* dx_bf16, int64_t lddx,
+                                   int M, int64_t K, int J, void* stream) {
+    GN_REQUIRE(dy_bf16 && w_bf16 && dx_bf16, GOALNET_E_NULL, "linear_bwd_dx_bf16_o16: null pointer");
+    GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_bf16_o16: bad dims");
+    GN_REQUIRE(J % BKH == 0 && K % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, GOALNET_E_SHAPE, "linear_bwd_dx_bf16_o16: J %% 64, K %% 8, lddx %% 8");
+    GN_REQUIRE(aligned16(dy_bf16) && aligned16(w_bf16) && aligned16(dx_bf16), GOALNET_E_ALIGN, "linear_bwd_dx_bf16_o16: alignment");
+    GN_REQUIRE(goalnet_linear_bwd_dx_bf16_o16_ok(M, K, J), GOALNET_E_SHAPE,
+               "linear_bwd_dx_bf16_o16: dims not served (ask goalnet_linear_bwd_dx_bf16_o16_ok; use goalnet_linear_bwd_dx_bf16)");
+    return launch_linear_dx_bf16_256("linear_bwd_dx_bf16_o16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)w_bf16, M, K,
+                                     J, nullptr, (__hip_bfloat16*)dx_bf16, lddx, (hipStream_t)stream);
 }
 
 /* dw[j][k] = sum_m dy_bf16[m][j] * x_bf16[m][k]   (fp32 out) */

@@ -377,6 +377,45 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
     const int r4 = r & ~3;
+    if constexpr (ROLE == 1 || ROLE == 4) {
+        // bf16 result (the gradient wrt a BatchNorm output, consumed by two HBM-bound passes): after the quad transpose
+        // lanes l and l ^ 4 hold columns c..c+3 and c+4..c+7 of the same rows for two register groups (rows 8 apart);
+        // they swap one packed group so that each stores 8 consecutive bf16 (16 B) of ONE row: 16 store instructions
+        // per wave for the tile (the fp32 form needs 32) and half the bytes.
+        if (ep.out16) {
+            __hip_bfloat16* o16 = reinterpret_cast<__hip_bfloat16*>(ep.out16);
+            const int hi = (lane >> 2) & 1;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int col4 = tn * T + (TRB ? ni * 128 + 16 * wc + (r4 & 15) + 64 * (r4 >> 4) : wc * 64 + ni * 32 + r4);
+                    const int col8 = col4 - 4 * hi;                                                    // first of this lane's 8 columns
+                    const bool colok = col8 < ep.cols;                                                 // cols % 8 == 0
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int g = 2 * gp + k;
+                            float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
+                            quad_transpose4(n0, n1, n2, n3, lane);
+                            pk[k][0] = pack2_bf16(n0, n1); pk[k][1] = pack2_bf16(n2, n3);
+                        }
+                        // lane hi = 0 keeps group 2gp and gets the partner's 2gp (its columns + 4); hi = 1 keeps 2gp + 1
+                        const unsigned s0 = hi ? pk[0][0] : pk[1][0], s1 = hi ? pk[0][1] : pk[1][1];
+                        const unsigned q0 = (unsigned)__shfl_xor((int)s0, 4, 64), q1 = (unsigned)__shfl_xor((int)s1, 4, 64);
+                        const unsigned m0 = hi ? pk[1][0] : pk[0][0], m1 = hi ? pk[1][1] : pk[0][1];
+                        const int i = (lane & 3) + 8 * (2 * gp + hi) + 4 * hh;
+                        const int64_t row = (int64_t)tm * T + (TRA ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (i & 15) + 64 * (i >> 4)
+                                                                   : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + i);
+                        if (colok && row < ep.rows)
+                            *reinterpret_cast<uint4*>(o16 + row * ep.ld + col8) = hi ? make_uint4(q0, q1, m0, m1) : make_uint4(m0, m1, q0, q1);
+                    }
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -486,7 +525,7 @@ int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_
 
 // dx[M][K] (fp32) = dy[M][J] . w[J][K]: A K-contiguous (reduction index j), B row-contiguous; no split (J / 64 K-tiles)
 int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
-                              int J, float* dx, int64_t lddx, hipStream_t st) {
+                              int J, float* dx, __hip_bfloat16* dx16, int64_t lddx, hipStream_t st) {
     typedef KCLoader256<64> AL;
     typedef MCLoader256 BL;
     static bool attr_set = false;
@@ -499,7 +538,7 @@ int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     AL::P ap{dy, lddy, M, 0};
     BL::P bp{w, K, (int)K, J};
-    EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0, dx16};
     hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 4>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
                        (int)tiles_m, (int)tiles_n, 1, J / BKH, J / BKH);
     GN_LAUNCH_CHECK(name);

@@ -18,6 +18,11 @@ constexpr unsigned OOB = 0xFFFFFF00u;
 
 __device__ __forceinline__ int kc_boff(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {          // round-to-nearest-even, a in the low half
+    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -37,7 +42,7 @@ int linear_fwd_splits_256(int M, int64_t K, int J);
 int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_t ldx, const __hip_bfloat16* w, int M, int64_t K,
                                int J, float* slabs, int nsplit, hipStream_t st);
 int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
-                              int J, float* dx, int64_t lddx, hipStream_t st);
+                              int J, float* dx, __hip_bfloat16* dx16, int64_t lddx, hipStream_t st);
 int launch_linear_dw_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* x, int64_t ldx, int M,
                               int64_t K, int J, float* dw, hipStream_t st);
 int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,

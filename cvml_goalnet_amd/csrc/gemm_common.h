@@ -21,6 +21,7 @@ struct EpiP {
     const float* mul; int64_t ldmul;      // elementwise multiplier (dropout mask forward, saved mult backward)
     float* mult_out; int64_t ldmo;        // (pre-activation > 0) * mul, saved for backward
     int64_t slab_stride;                  // > 0: raw partial sums to out + split * slab_stride (ld = cols)
+    void* out16;                          // non-null (256^2 bf16 kernel, raw epilogue only): the result as bf16 [rows][ld] instead of `out`
 };
 
 __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {

@@ -156,8 +156,24 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
 }
 
+// dz (the gradient wrt the BatchNorm output) arrives as fp32 or, from the bf16 GEMMs' bf16-output epilogue, as bf16
+__device__ __forceinline__ float4 load_dz4(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ float4 load_dz4(const __hip_bfloat16* q) {
+    const uint2 u = *reinterpret_cast<const uint2*>(q);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+// the same in two steps for software-pipelined loops: the raw load is issued early, the conversion waits for it later
+__device__ __forceinline__ float4 load_dz4_raw(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ uint2 load_dz4_raw(const __hip_bfloat16* q) { return *reinterpret_cast<const uint2*>(q); }
+__device__ __forceinline__ float4 dz4_of(const float4& v) { return v; }
+__device__ __forceinline__ float4 dz4_of(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
 // ---- backward phase 1: partial sums of dz and dz * xhat
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+template <typename DZ>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict__ dz, const float* __restrict__ p,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            double* __restrict__ partials, int64_t npix, int C) {
     __shared__ double smem[256 * 8];
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const float4 is = *reinterpret_cast<const float4*>(invstd + g * 4);
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int64_t pix = (int64_t)blockIdx.x * ppi + pl; pix < npix; pix += (int64_t)gridDim.x * ppi) {
-        const float4 d = *reinterpret_cast<const float4*>(dz + pix * C + g * 4);
+        const float4 d = load_dz4(dz + pix * C + g * 4);
         const float4 x = *reinterpret_cast<const float4*>(p + pix * C + g * 4);
         acc[0][0] += (double)d.x; acc[1][0] += (double)d.x * (double)((x.x - mu.x) * is.x);
         acc[0][1] += (double)d.y; acc[1][1] += (double)d.y * (double)((x.y - mu.y) * is.y);
@@ -338,7 +354,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 }
 
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
-__global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+template <typename DZ, int NP>
+__global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const float* __restrict__ p,
                                                            const uint8_t* __restrict__ idx,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
                                                            __hip_bfloat16* __restrict__ dy_pad,
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
     for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {       // (frame, band of dy rows), as in the forward
         const int n = unit / bands, band = unit % bands;
         const int h0 = (int)((int64_t)Hc * band / bands), h1 = (int)((int64_t)Hc * (band + 1) / bands);
-        const float* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
+        const DZ* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
         const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + ((int64_t)n * ccn + sl) * Hp * Wp * CS + l8 * 4;                            // slice-major, see idx_off
         float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
@@ -370,30 +387,33 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const float* __restr
         // Software pipeline over rows: the loads of pooled row h+1 (dz, p, argmax) are issued into registers before row h is
         // gathered and land while it is computed. Without it every row paid a full global-load round trip between two
         // barriers: ~9 MB in flight chip-wide = 3.6 TB/s, which is what the kernel measured.
-        constexpr int MAXP = 5;                                  // passes of 32 pixels: Wp <= 136 by the LDS limit of the launcher
-        float4 rd[MAXP], rq[MAXP];
-        uint32_t ri[MAXP];
+        // NP = passes of 32 pixels per pooled row (launcher: ceil(Wp / 32) <= 5). Every pass loads unconditionally, from a
+        // clamped address when its pixel or row is past the end (never consumed): with a branch around each pass hipcc cannot
+        // count the loads in flight and waits for nearly all of them before each use (vmcnt(2)), i.e. one memory round trip
+        // per pass; the bf16 form converts at the use, not at the load, for the same reason.
+        decltype(load_dz4_raw(dzn)) rd[NP];
+        float4 rq[NP];
+        uint32_t ri[NP];
         const int hfirst = h0 > 2 ? h0 - 2 : 0;                  // dy row h gathers from pooled rows h-2..h: two warm-up rows
         auto prefetch = [&](int hr) {
+            const int hrc = hr < Hp ? hr : Hp - 1;
 #pragma unroll
-            for (int ps = 0; ps < MAXP; ++ps) {
-                const int x = px + 32 * ps;
-                if (hr < Hp && x < Wp) {
-                    const int64_t o = ((int64_t)hr * Wp + x) * C;
-                    rd[ps] = *reinterpret_cast<const float4*>(dzn + o);
-                    rq[ps] = *reinterpret_cast<const float4*>(pn + o);
-                    ri[ps] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)hr * Wp + x) * CS);
-                }
+            for (int ps = 0; ps < NP; ++ps) {
+                const int x = px + 32 * ps, xc = x < Wp ? x : Wp - 1;
+                const int64_t o = ((int64_t)hrc * Wp + xc) * C;
+                rd[ps] = load_dz4_raw(dzn + o);
+                rq[ps] = *reinterpret_cast<const float4*>(pn + o);
+                ri[ps] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)hrc * Wp + xc) * CS);
             }
         };
         prefetch(hfirst);
         for (int h = hfirst; h < h1; ++h) {
             if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
 #pragma unroll
-                for (int ps = 0; ps < MAXP; ++ps) {
+                for (int ps = 0; ps < NP; ++ps) {
                     const int x = px + 32 * ps;
                     if (x < Wp) {
-                        const float4 d = rd[ps], q = rq[ps];
+                        const float4 d = dz4_of(rd[ps]), q = rq[ps];
                         float4 v;
                         // the ReLU mask rides on p: every window whose argmax is a given conv pixel has p equal to that pixel's y
                         v.x = q.x > 0.f ? fmaf(ca.x, d.x, fmaf(cbv.x, q.x, cc.x)) : 0.f;
@@ -464,6 +484,20 @@ int row_bands(int nparts, int N, int rows) {
     return b < 1 ? 1 : b;
 }
 
+template <typename DZ>
+static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const float* p, const uint8_t* idx, const float* coef3,
+                                 float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
+    const dim3 grid(nparts * (C / CS)), block(256);
+    const int bands = row_bands(nparts, N, Hc);
+    switch ((Wc - 2 + 31) / 32) {                               // passes of 32 pixels per pooled row; the LDS limit keeps Wp <= 136
+    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 1>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 2>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 3>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 4>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 5>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    }
+}
+
 bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >> 2)) == 0; }
 
 }  // namespace
@@ -513,8 +547,20 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
     GN_PARTS_OK("bn_bwd_reduce");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
     GN_LAUNCH_CHECK("bn_bwd_reduce");
+    return 0;
+}
+
+int goalnet_bn_bwd_reduce_dz16(const void* dz_bf16, const float* p, const float* mean, const float* invstd,
+                               double* partials, int nparts, int64_t npix, int C, void* stream) {
+    GN_REQUIRE(dz_bf16 && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce_dz16: null pointer");
+    GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_dz16: bad dims");
+    GN_PARTS_OK("bn_bwd_reduce_dz16");
+    GN_REQUIRE(aligned16(dz_bf16) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce_dz16: alignment");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nparts), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)dz_bf16, p, mean, invstd, partials, npix, C);
+    GN_LAUNCH_CHECK("bn_bwd_reduce_dz16");
     return 0;
 }
 
@@ -539,8 +585,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
-        hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, coef3,
-                           dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
+        launch_bnpool_bwd_v2<float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
@@ -560,9 +605,25 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    hipLaunchKernelGGL(bnpool_bwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, dz, p, idx, coef3,
-                       dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C, row_bands(nparts, N, Hc));
+    launch_bnpool_bwd_v2<float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
+    return 0;
+}
+
+int goalnet_bnpool_bwd_bf16p_dz16(const void* dz_bf16, const float* p, const uint8_t* idx, const float* coef3,
+                                  float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                                  void* stream) {
+    GN_REQUIRE(dz_bf16 && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_dz16: null pointer");
+    GN_PARTS_OK("bnpool_bwd_bf16p_dz16");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_dz16: bad dims (C %% 32)");
+    GN_REQUIRE(aligned16(dz_bf16) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p_dz16: alignment");
+    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_dz16: image too wide for the rolling LDS rows");
+    const size_t need = lds < 8192 ? 8192 : lds;
+    launch_bnpool_bwd_v2<__hip_bfloat16>(nparts, need, (hipStream_t)stream, (const __hip_bfloat16*)dz_bf16, p, idx, coef3, dy,
+                                         (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bnpool_bwd_bf16p_dz16");
     return 0;
 }
 

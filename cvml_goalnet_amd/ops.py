@@ -130,8 +130,13 @@ def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mea
 
 
 def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
+    """dz: fp32, or bf16 as the *_o16 GEMMs write it"""
     _chk(dz, p, mean, invstd, partials)
     assert dz.numel() == p.numel() == npix * C
+    if dz.dtype == torch.bfloat16:
+        check(lib().goalnet_bn_bwd_reduce_dz16(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
+                                               _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce_dz16")
+        return
     check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
                                       _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce")
 
@@ -154,6 +159,11 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
 def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dypad, dbias_partials)
     assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
+    if dz.dtype == torch.bfloat16:
+        check(lib().goalnet_bnpool_bwd_bf16p_dz16(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
+                                                  dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
+              "bnpool_bwd_bf16p_dz16")
+        return
     check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
                                          dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
           "bnpool_bwd_bf16p")
@@ -254,6 +264,19 @@ def conv3x3_fwd_bf16p(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     return y
 
 
+def conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout) -> bool:
+    return bool(lib().goalnet_conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout))
+
+
+def conv3x3_fwd_bf16p_o16(xpad, w, y, N, H, W, Cin, Cout):
+    """bf16 result, no bias / ReLU (data gradient); only for dims conv3x3_fwd_bf16p_o16_ok accepts"""
+    _chk(xpad, w, y)
+    assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == BF16
+    assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), y.data_ptr(), N, H, W, Cin, Cout, _s()), "conv3x3_fwd_bf16p_o16")
+    return y
+
+
 def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
     _chk(xpad, dypad, dw)
     assert xpad.dtype == BF16 and dypad.dtype == BF16 and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin
@@ -272,6 +295,21 @@ def linear_bwd_dx_bf16(dy, w, dx, mult=None):
     assert w.numel() == J * K and dx.shape[0] == M
     check(lib().goalnet_linear_bwd_dx_bf16(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
                                            dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_bf16")
+    return dx
+
+
+def linear_bwd_dx_bf16_o16_ok(M, K, J) -> bool:
+    return bool(lib().goalnet_linear_bwd_dx_bf16_o16_ok(M, K, J))
+
+
+def linear_bwd_dx_bf16_o16(dy, w, dx):
+    """bf16 result; only for dims linear_bwd_dx_bf16_o16_ok accepts"""
+    _chk(dy, w, dx)
+    assert dy.dtype == BF16 and w.dtype == BF16 and dx.dtype == BF16
+    M, J = dy.shape
+    K = dx.shape[1]
+    assert w.numel() == J * K and dx.shape[0] == M
+    check(lib().goalnet_linear_bwd_dx_bf16_o16(dy.data_ptr(), _ld(dy), w.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_bf16_o16")
     return dx
 
 

@@ -82,6 +82,9 @@ int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, 
 /* BatchNorm backward, phase 1: per-channel sum(dz) and sum(dz * xhat) -> partials (double). */
 int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
                           double* partials, int nparts, int64_t npix, int C, void* stream);
+/* same with dz as bf16 (written by goalnet_linear_bwd_dx_bf16_o16 / goalnet_conv3x3_fwd_bf16p_o16) */
+int goalnet_bn_bwd_reduce_dz16(const void* dz_bf16, const float* p, const float* mean, const float* invstd,
+                               double* partials, int nparts, int64_t npix, int C, void* stream);
 /* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
 int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
@@ -96,6 +99,10 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                              void* stream);
+/* same with dz as bf16 */
+int goalnet_bnpool_bwd_bf16p_dz16(const void* dz_bf16, const float* p, const uint8_t* idx, const float* coef3,
+                                  float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                                  void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
@@ -145,11 +152,22 @@ int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shif
 size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout);   /* split-K slabs, as goalnet_conv3x3_fwd */
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* The same convolution with its result stored as bf16 [N][H][W][Cout], no bias / ReLU: the data-gradient use (w = flipped
+ * weights), whose result — the gradient wrt a BatchNorm output — is only read by two HBM-bound passes
+ * (goalnet_bn_bwd_reduce_dz16, goalnet_bnpool_bwd_bf16p_dz16). fp32 accumulation, one rounding at the store. Served by the
+ * 256 x 256 tile only: goalnet_conv3x3_fwd_bf16p_o16_ok() says whether the dims are; otherwise use the fp32-output form. */
+int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout);
+int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, void* y_bf16, int N, int H, int W, int Cin, int Cout,
+                                  void* stream);
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
                                int N, int H, int W, int Cin, int Cout, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
                                float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
+/* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */
+int goalnet_linear_bwd_dx_bf16_o16_ok(int M, int64_t K, int J);
+int goalnet_linear_bwd_dx_bf16_o16(const void* dy_bf16, int64_t lddy, const void* w_bf16, void* dx_bf16, int64_t lddx,
+                                   int M, int64_t K, int J, void* stream);
 int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_bf16, int64_t ldx, float* dw,
                                int M, int64_t K, int J, void* stream);
 

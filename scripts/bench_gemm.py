@@ -102,6 +102,10 @@ def pool_case(name, hc, wc, c):
     t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dz, p, idx, coef3, None, dyp, dparts, n, hc, wc, c))
     gb = (dz.numel() * 4 + p.numel() * 5 + y.numel() * 2) / 1e9
     print(f"{name} bnpool bwd (bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    dzb = dz.to(torch.bfloat16)
+    t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dzb, p, idx, coef3, None, dyp, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 2 + p.numel() * 5 + y.numel() * 2) / 1e9
+    print(f"{name} bnpool bwd (bf16 dz, bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
 
 
 if len(sys.argv) > 2 and sys.argv[2] == "pool":

@@ -518,3 +518,67 @@ def test_phased_256_kernels_at_the_sizes_that_select_them(monkeypatch):
     scale = ref.abs().max().item()
     assert (res["auto"][:8].double() - ref).abs().max().item() <= 3e-6 * scale
     assert (res["auto"] - res["128"]).abs().max().item() <= 2e-5 * scale, "linear weight gradient"
+
+
+@pytest.mark.parametrize("tile", ["256"])
+def test_bf16_gradient_outputs_equal_the_fp32_outputs_rounded_once(tile, monkeypatch):
+    """The *_o16 forms of the two data-gradient GEMMs store bf16(accumulator): they must equal, bit for bit, the fp32-output
+    forms rounded to nearest-even — on whole tiles and on ragged edges (rows and columns that are not multiples of 256)."""
+    monkeypatch.setenv("GOALNET_BF16_TILE", tile)                        # small shapes through the 256 x 256 kernel
+    g = torch.Generator().manual_seed(91)
+    # linear dX: M frames x K features from J = 128
+    m, j, k = 70, 128, 1032
+    dy = (torch.rand(m, j, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    w = (torch.rand(j, k, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    assert ops.linear_bwd_dx_bf16_o16_ok(m, k, j)
+    f32 = ops.linear_bwd_dx_bf16(dy, w, torch.empty(m, k, device=DEV))
+    b16 = ops.linear_bwd_dx_bf16_o16(dy, w, torch.full((m, k), float("nan"), dtype=torch.bfloat16, device=DEV))
+    assert torch.equal(b16, f32.to(torch.bfloat16))
+    close("linear_bwd_dx_bf16_o16 vs fp64", b16.float(), (dy.double() @ w.double()), rtol=4e-3)      # bf16 rounding: 2^-9
+    # conv data gradient form: 3x3 conv of a padded bf16 tensor, no bias / ReLU
+    n, h, wd, cin, cout = 3, 9, 11, 64, 72
+    x = (torch.rand(n, h, wd, cin, generator=g) - 0.5)
+    wt = ((torch.rand(cout, 3, 3, cin, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    _, xp = _padded(x)
+    assert ops.conv3x3_fwd_bf16p_o16_ok(n, h, wd, cin, cout)
+    f32 = ops.conv3x3_fwd_bf16p(xp, wt, None, False, torch.empty(n, h, wd, cout, device=DEV), n, h, wd, cin, cout)
+    b16 = ops.conv3x3_fwd_bf16p_o16(xp, wt, torch.full((n, h, wd, cout), float("nan"), dtype=torch.bfloat16, device=DEV), n, h, wd, cin, cout)
+    assert torch.equal(b16, f32.to(torch.bfloat16))
+    monkeypatch.setenv("GOALNET_BF16_TILE", "128")                       # the 128 x 128 kernels have no bf16 epilogue: must refuse
+    assert not ops.linear_bwd_dx_bf16_o16_ok(m, k, j) and not ops.conv3x3_fwd_bf16p_o16_ok(n, h, wd, cin, cout)
+    with pytest.raises(Exception):
+        ops.linear_bwd_dx_bf16_o16(dy, w, torch.empty(m, k, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.mark.parametrize("n,hc,wc,c", [(3, 9, 11, 64), (2, 13, 13, 256)])
+def test_batchnorm_backward_passes_with_bf16_gradient_input(n, hc, wc, c):
+    """bn_bwd_reduce and the fused BN/pool/ReLU backward fed a bf16 dz must equal, bit for bit, the same kernels fed
+    those values as fp32."""
+    g = torch.Generator().manual_seed(92)
+    hp, wp = hc - 2, wc - 2
+    y = (torch.rand(n, hc, wc, c, generator=g) - 0.3).to(DEV)
+    p = torch.empty(n, hp, wp, c, device=DEV)
+    idx = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=DEV)
+    parts = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=DEV)
+    ops.pool_bnstats_fwd(y, p, idx, parts, n, hc, wc, c)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV); beta = torch.zeros(c, device=DEV)
+    st = torch.empty(4, c, device=DEV)
+    ops.bn_finalize(parts, gamma, beta, None, None, 0.1, 1e-5, n * hp * wp, c, st[0], st[1], st[2], st[3])
+    dz16 = (torch.rand(n, hp, wp, c, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    dz32 = dz16.float()
+    npix = n * hp * wp
+    out = {}
+    for name, dz in (("f32", dz32), ("b16", dz16)):
+        red = torch.empty(ops.stat_parts(max(npix // 64, 1)) * 2 * c, dtype=torch.float64, device=DEV)
+        ops.bn_bwd_reduce(dz, p, st[0], st[1], red, npix, c)
+        coef3 = torch.empty(3 * c, device=DEV); dg = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
+        ops.bn_bwd_finalize(red, gamma, st[0], st[1], npix, c, dg, db, coef3)
+        buf, dyp = ops.padded_bf16_alloc(n, hc, wc, c, DEV)
+        buf.zero_()
+        dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=DEV)
+        dy = torch.empty(n, hc, wc, c, device=DEV)
+        ops.bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dyp, dparts, n, hc, wc, c)
+        out[name] = (red.clone(), dg, db, coef3, dy, buf.clone(), dparts)
+    for a, b in zip(out["f32"], out["b16"]):
+        assert torch.equal(a, b)
+    assert out["b16"][4].abs().max().item() > 0
