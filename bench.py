@@ -266,6 +266,15 @@ def main():
         except Exception as e:
             log(f"parity probe failed: {e!r}")
         torch.cuda.empty_cache()            # the probe's 16-frame buffers must not fragment the pool the 1024-frame steps use
+    if distributed:
+        # RCCL builds its communicator, channels and staging buffers lazily on the first collectives of each kind (seen with one
+        # forced rank: +80 ms per step over the first steps): get that out of the way before the W warm-up steps
+        for dt_ in (torch.float32, torch.bfloat16):
+            t = torch.zeros(64 << 20, dtype=dt_, device=dev)
+            for _ in range(2):
+                dist.all_reduce(t)
+        torch.cuda.synchronize()
+        del t
     for _ in range(args.warmup):
         model.train_step(aud, vis, lab)
     model.kernel_events = {}
