@@ -5,6 +5,7 @@
 // Stride = kernel = 3, so the 3x3x3 input patches of neighbouring outputs are disjoint: every input
 // element is read exactly once. Input is the reference's NCHW frame tensor (read coalesced along W);
 // output is NHWC for the implicit-GEMM blocks that follow.
+#include <stdlib.h>
 #include "common.h"
 
 using namespace goalnet;
@@ -76,6 +77,55 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 o[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+        }
+    }
+}
+
+// v2: one output ROW (n, oh) per iteration, like the weight gradient below: the 9 input row segments (3 channels x 3
+// kernel rows) the row needs are contiguous in the NCHW frame and are staged coalesced, with the zero padding; v1 gathered
+// 27 scalars per pixel with 64-bit divisions (1.05 ms at N = 1024, 224 x 224 against 0.42 ms of HBM time). Thread =
+// (4 output channels, one of 16 pixels per pass); the 27-term chain runs in v1's order (bias, then k ascending): same bits.
+// Measured: 1.07 -> 0.9-1.0 ms only — what is left is one global round trip per row between two barriers.
+__global__ __launch_bounds__(256) void conv1_fwd_v2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int N, int H, int W, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int XW = 3 * Wo;
+    float* wsh = sm;                 // [KP][CO]: few registers -> 8 waves per SIMD hide the per-row load latency
+    float* xs = sm + KP * CO;        // [9][XW]   row r = ci*3 + kh, element j <-> iw = j - 3
+    const int tid = threadIdx.x;
+    const int cg = tid & 15, pl = tid >> 4;
+    for (int i = tid; i < KP * CO; i += 256) {
+        const int co = i / KP, k = i - co * KP;      // w is [co][kh][kw][ci]
+        wsh[k * CO + co] = w[i];
+    }
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + cg * 4);
+    const int nrows = N * Ho;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / Ho, oh = row - n * Ho;
+        __syncthreads();
+        for (int i = tid; i < 9 * XW; i += 256) {
+            const int r = i / XW, j = i - r * XW;
+            const int ci = r / 3, kh = r - 3 * ci;
+            const int ih = 3 * oh - 3 + kh, iw = j - 3;
+            float v = 0.f;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[(((int64_t)n * 3 + ci) * H + ih) * W + iw];
+            xs[i] = v;
+        }
+        __syncthreads();
+        // hipcc otherwise vectorises two pixels together (v_pk_fma_f32), needs 256 VGPRs (one wave per SIMD) and splits the stores
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (int ow = pl; ow < Wo; ow += 16) {
+            float4 a = b4;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int ci = k % 3, t = k / 3, kh = t / 3, kw = t - 3 * kh;
+                const float xv = xs[(ci * 3 + kh) * XW + 3 * ow + kw];
+                const float4 wk = *reinterpret_cast<const float4*>(&wsh[k * CO + cg * 4]);
+                a.x = fmaf(xv, wk.x, a.x); a.y = fmaf(xv, wk.y, a.y); a.z = fmaf(xv, wk.z, a.z); a.w = fmaf(xv, wk.w, a.w);
+            }
+            *reinterpret_cast<float4*>(y + ((int64_t)row * Wo + ow) * CO + cg * 4) =
+                make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
         }
     }
 }
@@ -184,6 +234,56 @@ __global__ __launch_bounds__(256) void conv1_wgrad_v2_kernel(const float* __rest
     if (kg == 0) prow[CO * KP + co] = accb;
 }
 
+// v3 (Wo % 4 == 0): thread = (co, r = ci*3 + kh) owns the three taps kw = 0..2 of one staged input row segment, so the x
+// values of four consecutive outputs are 12 consecutive floats = three ds_read_b128 (v2: seven scalar reads per output
+// for seven unrelated taps): 133 LDS reads per row and thread instead of 608 — v2 was LDS-bound (1.9 ms against 0.4 ms of
+// HBM time). Each tap still accumulates its products in output order, rows in the same order: same bits as v2.
+__global__ __launch_bounds__(576) void conv1_wgrad_v3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ partial, int N, int H, int W, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int XW = 3 * Wo;
+    float* xs = sm;                 // [9][XW]
+    float* dys = sm + 9 * XW;       // [Wo][64]
+    const int tid = threadIdx.x;
+    const int co = tid & 63, r = tid >> 6;          // r = ci*3 + kh  (0..8)
+    float acc[3] = {0.f, 0.f, 0.f};
+    float accb = 0.f;
+    const int nrows = N * Ho;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / Ho, oh = row - n * Ho;
+        __syncthreads();
+        for (int i = tid; i < 9 * XW; i += 576) {
+            const int rr = i / XW, j = i - rr * XW;
+            const int ci = rr / 3, kh = rr - 3 * ci;
+            const int ih = 3 * oh - 3 + kh, iw = j - 3;
+            float v = 0.f;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[(((int64_t)n * 3 + ci) * H + ih) * W + iw];
+            xs[i] = v;
+        }
+        const float4* src = reinterpret_cast<const float4*>(dy + (int64_t)row * Wo * CO);
+        for (int i = tid; i < Wo * (CO / 4); i += 576) reinterpret_cast<float4*>(dys)[i] = src[i];
+        __syncthreads();
+        const float4* xr = reinterpret_cast<const float4*>(xs + r * XW);
+        for (int o4 = 0; o4 < Wo / 4; ++o4) {
+            const float4 x0 = xr[3 * o4], x1 = xr[3 * o4 + 1], x2 = xr[3 * o4 + 2];
+            const float xv[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = dys[(4 * o4 + i) * CO + co];
+                if (r == 0) accb += d;
+                acc[0] = fmaf(d, xv[3 * i + 0], acc[0]);
+                acc[1] = fmaf(d, xv[3 * i + 1], acc[1]);
+                acc[2] = fmaf(d, xv[3 * i + 2], acc[2]);
+            }
+        }
+    }
+    float* prow = partial + (int64_t)blockIdx.x * (CO * KP + CO);
+    const int ci = r / 3, kh = r - 3 * ci;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) prow[co * KP + (kh * 3 + kw) * 3 + ci] = acc[kw];
+    if (r == 0) prow[CO * KP + co] = accb;
+}
+
 // 16 columns x 16 part lanes per block; lane-group totals added in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                 float* __restrict__ dw, float* __restrict__ db) {
@@ -221,10 +321,18 @@ int goalnet_conv1_fwd(const float* x_nchw, const float* w_ohwi, const float* bia
     GN_REQUIRE(aligned16(y_nhwc), GOALNET_E_ALIGN, "conv1_fwd: output must be 16-byte aligned");
     const int Ho = (H + 3) / 3 + 1, Wo = (W + 3) / 3 + 1;
     const int64_t npix = (int64_t)N * Ho * Wo;
-    int64_t blocks = (npix + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_ohwi, bias,
-                       y_nhwc, N, H, W, Ho, Wo);
+    const size_t lds = (size_t)(KP * CO + 9 * 3 * Wo) * sizeof(float);
+    if (lds <= 64 * 1024 && aligned16(bias) && !getenv("GOALNET_CONV1_V1")) {
+        int64_t blocks = (int64_t)N * Ho;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(conv1_fwd_v2_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x_nchw, w_ohwi, bias,
+                           y_nhwc, N, H, W, Ho, Wo);
+    } else {
+        int64_t blocks = (npix + 63) / 64;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, w_ohwi, bias,
+                           y_nhwc, N, H, W, Ho, Wo);
+    }
     GN_LAUNCH_CHECK("conv1_fwd");
     return 0;
 }
@@ -241,7 +349,10 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
     GN_REQUIRE(ws_bytes >= goalnet_conv1_wgrad_ws_bytes(N, H, W), GOALNET_E_WORKSPACE, "conv1_wgrad: workspace too small");
     const int Ho = (H + 3) / 3 + 1, Wo = (W + 3) / 3 + 1;
     const size_t lds = (size_t)(9 * 3 * Wo + Wo * CO) * sizeof(float);
-    if (lds <= 64 * 1024)
+    if (lds <= 64 * 1024 && Wo % 4 == 0 && !getenv("GOALNET_CONV1_V1"))
+        hipLaunchKernelGGL(conv1_wgrad_v3_kernel, dim3(WG_PARTS), dim3(576), lds, (hipStream_t)stream, x_nchw, dy_nhwc,
+                           (float*)ws, N, H, W, Ho, Wo);
+    else if (lds <= 64 * 1024)
         hipLaunchKernelGGL(conv1_wgrad_v2_kernel, dim3(WG_PARTS), dim3(256), lds, (hipStream_t)stream, x_nchw, dy_nhwc,
                            (float*)ws, N, H, W, Ho, Wo);
     else

@@ -87,7 +87,8 @@ struct ConvAPadLoader256 {
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
         const int hw = p.H * p.W;
-        const int n0 = row0 / hw, r0 = row0 - n0 * hw, h0 = r0 / p.W, w0 = r0 - h0 * p.W;
+        const double inv_hw = 1.0 / (double)hw, inv_w = 1.0 / (double)p.W;       // rows and pixels stay below 2^31 (launcher)
+        const int n0 = fast_div(row0, inv_hw), r0 = row0 - n0 * hw, h0 = fast_div(r0, inv_w), w0 = r0 - h0 * p.W;
         const int64_t pm0 = ((int64_t)n0 * (p.H + 2) + h0 + 1) * Wp2 + w0 + 1;      // padded index of the tile's first pixel
         const int G = Wp2 + 1;
         // 256 consecutive output pixels span < 256 + 2 * (rows crossed + frames crossed * (W+2)) padded pixels. Only an
@@ -101,7 +102,7 @@ struct ConvAPadLoader256 {
                 const int lc = (lane & 7) ^ ((rl >> 1) & 7);
                 const int64_t m = (int64_t)row0 + tile_row_of<GROUP>(h, rl);
                 if (m < p.M) {
-                    const int n = (int)(m / hw), rr = (int)(m - (int64_t)n * hw), hh = rr / p.W, w = rr - hh * p.W;
+                    const int n = fast_div((int)m, inv_hw), rr = (int)m - n * hw, hh = fast_div(rr, inv_w), w = rr - hh * p.W;
                     const int64_t pm = ((int64_t)n * (p.H + 2) + hh + 1) * Wp2 + w + 1;
                     voff[h][i] = (unsigned)(((pm - pm0) * p.C + lc * 8) * 2);
                 } else {

@@ -111,3 +111,18 @@ def pool_case(name, hc, wc, c):
 if len(sys.argv) > 2 and sys.argv[2] == "pool":
     pool_case("block3 72x72x512", 72, 72, 512)
     pool_case("block2 74x74x256", 74, 74, 256)
+
+
+def conv1_case(h, w):
+    x = torch.rand(n, 3, h, w, device=dev); wt = torch.randn(64, 3, 3, 3, device=dev) * 0.1; b = torch.randn(64, device=dev)
+    ho, wo = (h + 3) // 3 + 1, (w + 3) // 3 + 1
+    y = torch.empty(n, ho, wo, 64, device=dev)
+    t, ta = timeit(lambda: ops.conv1_fwd(x, wt, b, y, n, h, w))
+    print(f"conv1 fwd   {h}x{w}: {t:8.3f} ms  {(x.numel() + y.numel()) * 4 / t / 1e6:7.0f} GB/s")
+    dy = torch.randn(n, ho, wo, 64, device=dev); dw = torch.empty(64, 3, 3, 3, device=dev); db = torch.empty(64, device=dev)
+    t, ta = timeit(lambda: ops.conv1_wgrad(x, dy, dw, db, n, h, w))
+    print(f"conv1 wgrad {h}x{w}: {t:8.3f} ms  {(x.numel() + dy.numel()) * 4 / t / 1e6:7.0f} GB/s")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "conv1":
+    conv1_case(224, 224)

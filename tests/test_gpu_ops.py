@@ -65,8 +65,8 @@ def test_layout_converters_exact():
     assert torch.equal(wt.cpu().view(12, 3, 3, 8), want)
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 40, 40), (3, 41, 38), (2, 7, 9)])
-def test_conv1_fwd_and_wgrad(n, h, w):
+@pytest.mark.parametrize("n,h,w", [(1, 40, 40), (3, 41, 38), (2, 7, 9), (2, 224, 224), (3, 33, 9)])
+def test_conv1_fwd_and_wgrad(n, h, w, monkeypatch):
     x = rnd(n, 3, h, w, seed=3, lo=0, hi=1)
     wt = rnd(64, 3, 3, 3, seed=4, lo=-0.2, hi=0.2)       # OIHW
     b = rnd(64, seed=5, lo=-0.2, hi=0.2)
@@ -87,6 +87,14 @@ def test_conv1_fwd_and_wgrad(n, h, w):
     ops.conv1_wgrad(x.to(DEV), dy.to(DEV), dw, db, n, h, w)
     close("conv1_wgrad.dw", dw, wd.grad.permute(0, 2, 3, 1), rtol=2e-5)
     close("conv1_wgrad.db", db, bd.grad, rtol=2e-5)
+    # the row-staged kernels keep the first generation's order of operations: identical bits
+    monkeypatch.setenv("GOALNET_CONV1_V1", "1")
+    y1 = torch.empty_like(y)
+    ops.conv1_fwd(x.to(DEV), w_ohwi, b.to(DEV), y1, n, h, w)
+    assert torch.equal(y, y1)
+    dw1, db1 = torch.empty_like(dw), torch.empty_like(db)
+    ops.conv1_wgrad(x.to(DEV), dy.to(DEV), dw1, db1, n, h, w)
+    assert torch.equal(dw, dw1) and torch.equal(db, db1)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,affine,bias,relu", [
