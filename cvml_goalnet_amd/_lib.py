@@ -37,13 +37,14 @@ PROTOTYPES = {
     "goalnet_conv1_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "goalnet_stat_parts": (c_int, [c_int64]),
     "goalnet_pool_bnstats_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_pool_bnstats_fwd_p16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bn_finalize": (c_int, [P, c_int, P, P, P, P, c_float, c_float, c_int64, c_int, P, P, P, P, P]),
     "goalnet_bn_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P]),
-    "goalnet_bn_bwd_reduce_dz16": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P]),
+    "goalnet_bn_bwd_reduce_t": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int64, c_int, P]),
     "goalnet_bn_bwd_finalize": (c_int, [P, c_int, P, P, P, c_int64, c_int, P, P, P, P]),
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bnpool_bwd_bf16p_dz16": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -53,11 +54,13 @@ PROTOTYPES = {
     "goalnet_cast_bf16": (c_int, [P, P, c_int64, P]),
     "goalnet_cast_f32": (c_int, [P, P, c_int64, P]),
     "goalnet_bn_apply_bf16": (c_int, [P, P, P, P, c_int64, c_int, P]),
+    "goalnet_bn_apply_bf16_p16": (c_int, [P, P, P, P, c_int64, c_int, P]),
     "goalnet_conv3x3_fwd_bf16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_linear_fwd_bf16_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "goalnet_linear_fwd_bf16": (c_int, [P, c_int64, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
     "goalnet_bf16_padded_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "goalnet_to_bf16_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_to_bf16_padded_p16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_conv3x3_fwd_bf16p_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -118,6 +118,7 @@ class AVM(nn.Module):
         self.grad_sync = None          # optional ddp.GradSync: gradient exchange between backward and Adam
         self.stat_sync = None          # optional ddp.SyncStats: BatchNorm sums and the loss over all ranks' frames
         self.grad_bf16 = os.environ.get("GOALNET_DZ16", "1") != "0"   # precision="bf16": bf16 BatchNorm-output gradients (backward_device)
+        self.act_bf16 = os.environ.get("GOALNET_P16", "1") != "0"     # precision="bf16": pooled activations of blocks 2, 3 stored as bf16
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
@@ -391,10 +392,12 @@ class AVM(nn.Module):
         ops.partials_sum_f64(partials, width, row)
         return self.stat_sync.all_reduce(row)
 
-    def _bn_block(self, y, n, hc, wc, c, i, save):
-        """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift)."""
+    def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
+        """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift).
+        p16: the pooled activation is stored as bf16 (precision="bf16", blocks whose every consumer is a bf16 GEMM pass)."""
         dev = self._device
-        p = torch.empty(n, hc - 2, wc - 2, c, dtype=F32, device=dev)
+        p16 = p16 and c % 32 == 0 and 3 * wc * 32 * 4 <= 65536          # what goalnet_pool_bnstats_fwd_p16 serves
+        p = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.bfloat16 if p16 else F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
         # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
         partials = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=dev)
@@ -447,7 +450,7 @@ class AVM(nn.Module):
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
-        p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save)
+        p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save, p16=bf and self.act_bf16)
         del y2
         y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
         if bf:
@@ -458,7 +461,10 @@ class AVM(nn.Module):
         else:
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
-        p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save)
+        # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
+        # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
+        bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
+        p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save, p16=bf5 and self.act_bf16)
         del y3
 
         fw = 640 if self.audio_included else 512
@@ -466,9 +472,6 @@ class AVM(nn.Module):
         cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
         mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         k5 = 512 * hp3 * wp3
-        # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
-        # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
-        bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
         if bf5:
             xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
             w5b = self._w5_bf16(k5)

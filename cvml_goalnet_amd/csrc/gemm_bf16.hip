@@ -455,14 +455,26 @@ __global__ __launch_bounds__(256) void cast_f32_kernel(const __hip_bfloat16* __r
     }
 }
 
+// 8 consecutive elements of an fp32 or bf16 tensor as two float4
+__device__ __forceinline__ void load8(const float* x, int64_t i, float4& a, float4& b) {
+    a = reinterpret_cast<const float4*>(x)[2 * i]; b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+}
+__device__ __forceinline__ void load8(const __hip_bfloat16* x, int64_t i, float4& a, float4& b) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+    a = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    b = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+}
+
 // y = bf16(x * scale[c] + shift[c]), c = element index mod C (NHWC), C % 8 == 0
-__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <typename XT>
+__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const XT* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
                                                            int64_t n8, int C) {
     const int c8n = C >> 3;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c8n) * 8;
-        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        float4 a, b;
+        load8(x, i, a, b);
         const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
         const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
         reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y)), pack2(fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w)),
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const float* __restr
 
 // x fp32 [N][H][W][C] -> bf16 zero-padded [N][H+2][W+2][C] (interior only; the caller zeroed the buffer once),
 // optional per-channel affine. One thread = 8 channels of one pixel.
-__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+template <typename XT>
+__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const XT* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
                                                             int64_t n8, int H, int W, int C) {
     const int c8n = C >> 3;
@@ -484,7 +497,8 @@ __global__ __launch_bounds__(256) void to_bf16_padded_kernel(const float* __rest
         const int h = (int)(t % H);
         const int64_t n = t / H;
         const int64_t pm = (n * (H + 2) + h + 1) * (W + 2) + w + 1;
-        float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        float4 a, b;
+        load8(x, i, a, b);
         if (scale) {
             const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
             const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
@@ -528,9 +542,19 @@ int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift
     GN_REQUIRE(x && scale && shift && y_bf16, GOALNET_E_NULL, "bn_apply_bf16: null pointer");
     GN_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, GOALNET_E_SHAPE, "bn_apply_bf16: n must be a multiple of C, C of 8");
     GN_REQUIRE(aligned16(x) && aligned16(y_bf16) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "bn_apply_bf16: alignment");
-    hipLaunchKernelGGL(bn_apply_bf16_kernel, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+    hipLaunchKernelGGL(bn_apply_bf16_kernel<float>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        (__hip_bfloat16*)y_bf16, n / 8, C);
     GN_LAUNCH_CHECK("bn_apply_bf16");
+    return 0;
+}
+
+int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream) {
+    GN_REQUIRE(x_bf16 && scale && shift && y_bf16, GOALNET_E_NULL, "bn_apply_bf16_p16: null pointer");
+    GN_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, GOALNET_E_SHAPE, "bn_apply_bf16_p16: n must be a multiple of C, C of 8");
+    GN_REQUIRE(aligned16(x_bf16) && aligned16(y_bf16) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "bn_apply_bf16_p16: alignment");
+    hipLaunchKernelGGL(bn_apply_bf16_kernel<__hip_bfloat16>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)x_bf16, scale, shift, (__hip_bfloat16*)y_bf16, n / 8, C);
+    GN_LAUNCH_CHECK("bn_apply_bf16_p16");
     return 0;
 }
 
@@ -619,9 +643,21 @@ int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shif
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, GOALNET_E_SHAPE, "to_bf16_padded: bad dims (C %% 8)");
     GN_REQUIRE(aligned16(x) && aligned16(y_pad) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "to_bf16_padded: alignment");
     const int64_t n8 = (int64_t)N * H * W * (C / 8);
-    hipLaunchKernelGGL(to_bf16_padded_kernel, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+    hipLaunchKernelGGL(to_bf16_padded_kernel<float>, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
                        (__hip_bfloat16*)y_pad, n8, H, W, C);
     GN_LAUNCH_CHECK("to_bf16_padded");
+    return 0;
+}
+
+int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream) {
+    GN_REQUIRE(x_bf16 && y_pad, GOALNET_E_NULL, "to_bf16_padded_p16: null pointer");
+    GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "to_bf16_padded_p16: scale/shift must both be set or both NULL");
+    GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, GOALNET_E_SHAPE, "to_bf16_padded_p16: bad dims (C %% 8)");
+    GN_REQUIRE(aligned16(x_bf16) && aligned16(y_pad) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "to_bf16_padded_p16: alignment");
+    const int64_t n8 = (int64_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(to_bf16_padded_kernel<__hip_bfloat16>, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)x_bf16, scale, shift, (__hip_bfloat16*)y_pad, n8, H, W, C);
+    GN_LAUNCH_CHECK("to_bf16_padded_p16");
     return 0;
 }
 

@@ -172,8 +172,8 @@ __device__ __forceinline__ float4 dz4_of(const uint2& u) {
 }
 
 // ---- backward phase 1: partial sums of dz and dz * xhat
-template <typename DZ>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict__ dz, const float* __restrict__ p,
+template <typename DZ, typename PT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            double* __restrict__ partials, int64_t npix, int C) {
     __shared__ double smem[256 * 8];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int64_t pix = (int64_t)blockIdx.x * ppi + pl; pix < npix; pix += (int64_t)gridDim.x * ppi) {
         const float4 d = load_dz4(dz + pix * C + g * 4);
-        const float4 x = *reinterpret_cast<const float4*>(p + pix * C + g * 4);
+        const float4 x = load_dz4(p + pix * C + g * 4);
         acc[0][0] += (double)d.x; acc[1][0] += (double)d.x * (double)((x.x - mu.x) * is.x);
         acc[0][1] += (double)d.y; acc[1][1] += (double)d.y * (double)((x.y - mu.y) * is.y);
         acc[0][2] += (double)d.z; acc[1][2] += (double)d.z * (double)((x.z - mu.z) * is.z);
@@ -288,7 +288,28 @@ __device__ __forceinline__ void slice_reduce_store(double (&v)[2][4], int nv, in
     }
 }
 
-__global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* __restrict__ y, float* __restrict__ p,
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
+}
+
+// the pooled activation p is stored as fp32 or (precision = "bf16", blocks 2 and 3) as bf16: it is read three more times per
+// step (BatchNorm apply, BatchNorm backward reduce, fused backward) and every GEMM behind it consumes bf16 anyway. The
+// statistics are taken from the values AS STORED, so forward and backward see one and the same activation.
+__device__ __forceinline__ float4 store_p4(float* q, const float4& v) { *reinterpret_cast<float4*>(q) = v; return v; }
+__device__ __forceinline__ float4 store_p4(__hip_bfloat16* q, const float4& v) {
+    const uint2 u = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    *reinterpret_cast<uint2*>(q) = u;
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 load_p4(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ float4 load_p4(const __hip_bfloat16* q) {
+    const uint2 u = *reinterpret_cast<const uint2*>(q);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename PT>
+__global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* __restrict__ y, PT* __restrict__ p,
                                                                  uint8_t* __restrict__ idx, double* __restrict__ partials,
                                                                  int N, int Hc, int Wc, int C, int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][Wc][CS] floats (>= 16 KB for the reduction)
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
         const int n = unit / bands, band = unit % bands;
         const int p0 = (int)((int64_t)Hp * band / bands), p1 = (int)((int64_t)Hp * (band + 1) / bands);
         const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
-        float* pn = p + (int64_t)n * Hp * Wp * C + c0;
+        PT* pn = p + (int64_t)n * Hp * Wp * C + c0;
         uint8_t* in = idx ? idx + ((int64_t)n * ccn + blockIdx.x % ccn) * Hp * Wp * CS + l8 * 4 : nullptr;     // slice-major, see idx_off
         __syncthreads();
         for (int rr = p0; rr < p0 + 2; ++rr)
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
                     }
                 }
                 const int64_t o = ((int64_t)ph * Wp + pw) * C;
-                *reinterpret_cast<float4*>(pn + o) = best;
+                best = store_p4(pn + o, best);
                 if (in) *reinterpret_cast<uint32_t*>(in + ((int64_t)ph * Wp + pw) * CS) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
                 acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
                 acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
@@ -348,14 +369,9 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
     slice_reduce_store(acc, 2, tid, reinterpret_cast<double*>(smem), row, row + C);
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
-    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
-}
-
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
-template <typename DZ, int NP>
-__global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const float* __restrict__ p,
+template <typename DZ, typename PT, int NP>
+__global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const uint8_t* __restrict__ idx,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
                                                            __hip_bfloat16* __restrict__ dy_pad,
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
         const int n = unit / bands, band = unit % bands;
         const int h0 = (int)((int64_t)Hc * band / bands), h1 = (int)((int64_t)Hc * (band + 1) / bands);
         const DZ* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
-        const float* pn = p + (int64_t)n * Hp * Wp * C + c0;
+        const PT* pn = p + (int64_t)n * Hp * Wp * C + c0;
         const uint8_t* in = idx + ((int64_t)n * ccn + sl) * Hp * Wp * CS + l8 * 4;                            // slice-major, see idx_off
         float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
         __hip_bfloat16* dpn = dy_pad ? dy_pad + (int64_t)n * (Hc + 2) * (Wc + 2) * C + c0 : nullptr;
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
         // count the loads in flight and waits for nearly all of them before each use (vmcnt(2)), i.e. one memory round trip
         // per pass; the bf16 form converts at the use, not at the load, for the same reason.
         decltype(load_dz4_raw(dzn)) rd[NP];
-        float4 rq[NP];
+        decltype(load_dz4_raw(pn)) rq[NP];
         uint32_t ri[NP];
         const int hfirst = h0 > 2 ? h0 - 2 : 0;                  // dy row h gathers from pooled rows h-2..h: two warm-up rows
         auto prefetch = [&](int hr) {
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
                 const int x = px + 32 * ps, xc = x < Wp ? x : Wp - 1;
                 const int64_t o = ((int64_t)hrc * Wp + xc) * C;
                 rd[ps] = load_dz4_raw(dzn + o);
-                rq[ps] = *reinterpret_cast<const float4*>(pn + o);
+                rq[ps] = load_dz4_raw(pn + o);
                 ri[ps] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)hrc * Wp + xc) * CS);
             }
         };
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
                 for (int ps = 0; ps < NP; ++ps) {
                     const int x = px + 32 * ps;
                     if (x < Wp) {
-                        const float4 d = dz4_of(rd[ps]), q = rq[ps];
+                        const float4 d = dz4_of(rd[ps]), q = dz4_of(rq[ps]);
                         float4 v;
                         // the ReLU mask rides on p: every window whose argmax is a given conv pixel has p equal to that pixel's y
                         v.x = q.x > 0.f ? fmaf(ca.x, d.x, fmaf(cbv.x, q.x, cc.x)) : 0.f;
@@ -484,17 +500,17 @@ int row_bands(int nparts, int N, int rows) {
     return b < 1 ? 1 : b;
 }
 
-template <typename DZ>
-static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const float* p, const uint8_t* idx, const float* coef3,
+template <typename DZ, typename PT>
+static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const PT* p, const uint8_t* idx, const float* coef3,
                                  float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
     const dim3 grid(nparts * (C / CS)), block(256);
     const int bands = row_bands(nparts, N, Hc);
     switch ((Wc - 2 + 31) / 32) {                               // passes of 32 pixels per pooled row; the LDS limit keeps Wp <= 136
-    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 1>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 2>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 3>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 4>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, 5>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 1>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 2>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 3>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 4>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 5>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
     }
 }
 
@@ -519,12 +535,29 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
-        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
+        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel<float>, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
                            partials, N, Hc, Wc, C, row_bands(nparts, N, Hc - 2));
     } else {
         hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("pool_bnstats_fwd");
+    return 0;
+}
+
+int goalnet_pool_bnstats_fwd_p16(const float* y, void* p_bf16, uint8_t* idx, double* partials, int nparts,
+                                 int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(y && p_bf16 && partials, GOALNET_E_NULL, "pool_bnstats_fwd_p16: null pointer");
+    GN_PARTS_OK("pool_bnstats_fwd_p16");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: need Hc, Wc >= 3");
+    GN_REQUIRE(chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: C=%d must be 32*2^k, <= 1024", C);
+    GN_REQUIRE(aligned16(y) && aligned16(p_bf16) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
+               "pool_bnstats_fwd_p16: pointers must be 16-byte aligned");
+    const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
+    GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: image too wide for the rolling LDS rows");
+    const size_t need = lds < 16384 ? 16384 : lds;
+    hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel<__hip_bfloat16>, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y,
+                       (__hip_bfloat16*)p_bf16, idx, partials, N, Hc, Wc, C, row_bands(nparts, N, Hc - 2));
+    GN_LAUNCH_CHECK("pool_bnstats_fwd_p16");
     return 0;
 }
 
@@ -547,20 +580,26 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
     GN_PARTS_OK("bn_bwd_reduce");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
     GN_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
 
-int goalnet_bn_bwd_reduce_dz16(const void* dz_bf16, const float* p, const float* mean, const float* invstd,
-                               double* partials, int nparts, int64_t npix, int C, void* stream) {
-    GN_REQUIRE(dz_bf16 && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce_dz16: null pointer");
-    GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_dz16: bad dims");
-    GN_PARTS_OK("bn_bwd_reduce_dz16");
-    GN_REQUIRE(aligned16(dz_bf16) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce_dz16: alignment");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<__hip_bfloat16>, dim3(nparts), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)dz_bf16, p, mean, invstd, partials, npix, C);
-    GN_LAUNCH_CHECK("bn_bwd_reduce_dz16");
+/* dz and p each fp32 (flag 0) or bf16 (flag 1) */
+int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const float* mean, const float* invstd,
+                            double* partials, int nparts, int64_t npix, int C, void* stream) {
+    GN_REQUIRE(dz && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce_t: null pointer");
+    GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_t: bad dims");
+    GN_PARTS_OK("bn_bwd_reduce_t");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce_t: alignment");
+    const dim3 grid(nparts), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    typedef __hip_bfloat16 bf;
+    if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C);
+    else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C);
+    else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    GN_LAUNCH_CHECK("bn_bwd_reduce_t");
     return 0;
 }
 
@@ -585,7 +624,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
-        launch_bnpool_bwd_v2<float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
+        launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
                            dbias_partials, N, Hc, Wc, C);
@@ -605,25 +644,31 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    launch_bnpool_bwd_v2<float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+    launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;
 }
 
-int goalnet_bnpool_bwd_bf16p_dz16(const void* dz_bf16, const float* p, const uint8_t* idx, const float* coef3,
-                                  float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                                  void* stream) {
-    GN_REQUIRE(dz_bf16 && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_dz16: null pointer");
-    GN_PARTS_OK("bnpool_bwd_bf16p_dz16");
-    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_dz16: bad dims (C %% 32)");
-    GN_REQUIRE(aligned16(dz_bf16) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
-               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p_dz16: alignment");
+/* dz and p each fp32 (flag 0) or bf16 (flag 1) */
+int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
+                               float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                               void* stream) {
+    GN_REQUIRE(dz && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_t: null pointer");
+    GN_PARTS_OK("bnpool_bwd_bf16p_t");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: bad dims (C %% 32)");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p_t: alignment");
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
-    GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_dz16: image too wide for the rolling LDS rows");
+    GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    launch_bnpool_bwd_v2<__hip_bfloat16>(nparts, need, (hipStream_t)stream, (const __hip_bfloat16*)dz_bf16, p, idx, coef3, dy,
-                                         (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
-    GN_LAUNCH_CHECK("bnpool_bwd_bf16p_dz16");
+    hipStream_t st = (hipStream_t)stream;
+    typedef __hip_bfloat16 bf;
+    bf* dp = (bf*)dy_pad_bf16;
+    if (dz_bf16 && p_bf16) launch_bnpool_bwd_v2<bf, bf>(nparts, need, st, (const bf*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (dz_bf16)      launch_bnpool_bwd_v2<bf, float>(nparts, need, st, (const bf*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (p_bf16)       launch_bnpool_bwd_v2<float, bf>(nparts, need, st, (const float*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else                   launch_bnpool_bwd_v2<float, float>(nparts, need, st, (const float*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bnpool_bwd_bf16p_t");
     return 0;
 }
 

@@ -116,6 +116,10 @@ def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     _chk(y, p, idx, partials)
     assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
     assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
+    if p.dtype == torch.bfloat16:                   # pooled activation stored as bf16 (statistics of the stored values)
+        check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
+                                                 N, Hc, Wc, C, _s()), "pool_bnstats_fwd_p16")
+        return
     check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
                                          N, Hc, Wc, C, _s()), "pool_bnstats_fwd")
 
@@ -130,12 +134,13 @@ def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mea
 
 
 def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
-    """dz: fp32, or bf16 as the *_o16 GEMMs write it"""
+    """dz: fp32, or bf16 as the *_o16 GEMMs write it; p: fp32, or bf16 as pool_bnstats_fwd stores it into a bf16 tensor"""
     _chk(dz, p, mean, invstd, partials)
     assert dz.numel() == p.numel() == npix * C
-    if dz.dtype == torch.bfloat16:
-        check(lib().goalnet_bn_bwd_reduce_dz16(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
-                                               _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce_dz16")
+    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
+        check(lib().goalnet_bn_bwd_reduce_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
+                                            mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), _rows(partials, 2 * C), npix, C, _s()),
+              "bn_bwd_reduce_t")
         return
     check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
                                       _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce")
@@ -159,10 +164,10 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
 def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dypad, dbias_partials)
     assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
-    if dz.dtype == torch.bfloat16:
-        check(lib().goalnet_bnpool_bwd_bf16p_dz16(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
-                                                  dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
-              "bnpool_bwd_bf16p_dz16")
+    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
+        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
+                                               idx.data_ptr(), coef3.data_ptr(), _p(dy), dypad.data_ptr(), dbias_partials.data_ptr(),
+                                               _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p_t")
         return
     check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
                                          dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
@@ -223,7 +228,10 @@ def cast_f32(x, y):
 
 def bn_apply_bf16(x, scale, shift, y, C):
     _chk(x, scale, shift, y)
-    assert x.dtype == F32 and y.dtype == BF16 and x.numel() == y.numel() and scale.numel() == C
+    assert x.dtype in (F32, BF16) and y.dtype == BF16 and x.numel() == y.numel() and scale.numel() == C
+    if x.dtype == BF16:
+        check(lib().goalnet_bn_apply_bf16_p16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _s()), "bn_apply_bf16_p16")
+        return y
     check(lib().goalnet_bn_apply_bf16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _s()), "bn_apply_bf16")
     return y
 
@@ -248,7 +256,10 @@ def padded_bf16_alloc(N, H, W, C, device):
 
 def to_bf16_padded(x, scale, shift, ypad, N, H, W, C):
     _chk(x, scale, shift, ypad)
-    assert x.dtype == F32 and ypad.dtype == BF16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
+    assert x.dtype in (F32, BF16) and ypad.dtype == BF16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
+    if x.dtype == BF16:
+        check(lib().goalnet_to_bf16_padded_p16(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _s()), "to_bf16_padded_p16")
+        return ypad
     check(lib().goalnet_to_bf16_padded(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _s()), "to_bf16_padded")
     return ypad
 

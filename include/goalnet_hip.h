@@ -74,6 +74,10 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
  * partials[nparts][2][C] (double) = per-block sum and sum of squares of p. */
 int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials, int nparts,
                              int N, int Hc, int Wc, int C, void* stream);
+/* The same with the pooled activation stored as bf16 (C % 32 == 0): precision = "bf16" keeps p of blocks 2 and 3 in bf16 — it is
+ * read three more times per step and every GEMM behind it consumes bf16. The statistics are those of the values as stored. */
+int goalnet_pool_bnstats_fwd_p16(const float* y, void* p_bf16, uint8_t* idx, double* partials, int nparts,
+                                 int N, int Hc, int Wc, int C, void* stream);
 /* mean/biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated
  * with `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
 int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, const float* beta,
@@ -82,9 +86,10 @@ int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, 
 /* BatchNorm backward, phase 1: per-channel sum(dz) and sum(dz * xhat) -> partials (double). */
 int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, const float* invstd,
                           double* partials, int nparts, int64_t npix, int C, void* stream);
-/* same with dz as bf16 (written by goalnet_linear_bwd_dx_bf16_o16 / goalnet_conv3x3_fwd_bf16p_o16) */
-int goalnet_bn_bwd_reduce_dz16(const void* dz_bf16, const float* p, const float* mean, const float* invstd,
-                               double* partials, int nparts, int64_t npix, int C, void* stream);
+/* same with dz and p each fp32 (flag 0) or bf16 (flag 1): dz as goalnet_linear_bwd_dx_bf16_o16 / goalnet_conv3x3_fwd_bf16p_o16
+ * write it, p as goalnet_pool_bnstats_fwd_p16 stores it */
+int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const float* mean, const float* invstd,
+                            double* partials, int nparts, int64_t npix, int C, void* stream);
 /* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
 int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
@@ -99,10 +104,10 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                              void* stream);
-/* same with dz as bf16 */
-int goalnet_bnpool_bwd_bf16p_dz16(const void* dz_bf16, const float* p, const uint8_t* idx, const float* coef3,
-                                  float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                                  void* stream);
+/* same with dz and p each fp32 (flag 0) or bf16 (flag 1) */
+int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
+                               float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
+                               void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
@@ -134,6 +139,7 @@ int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
 int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
 /* y_bf16 = bf16(x * scale[c] + shift[c]), c = i mod C: the BatchNorm output utils.py:177/182/187, materialised in bf16 */
 int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);
+int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);   /* bf16 input */
 /* y = [relu](conv3x3(x_bf16 NHWC, w_bf16 OHWI) + bias), fp32 out; Cin % 64 == 0. Data gradient with flipped weights. */
 int goalnet_conv3x3_fwd_bf16(const void* x_bf16, const void* w_bf16, const float* bias, int relu, float* y,
                              int N, int H, int W, int Cin, int Cout, void* stream);
@@ -149,6 +155,7 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
  * the caller zeroes the whole buffer once (only interior pixels are ever written). */
 int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems, int64_t* offset_elems);
 int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);
+int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);   /* bf16 input */
 size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout);   /* split-K slabs, as goalnet_conv3x3_fwd */
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);

@@ -590,3 +590,53 @@ def test_batchnorm_backward_passes_with_bf16_gradient_input(n, hc, wc, c):
     for a, b in zip(out["f32"], out["b16"]):
         assert torch.equal(a, b)
     assert out["b16"][4].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("n,hc,wc,c", [(3, 9, 11, 64), (2, 13, 13, 256), (2, 40, 37, 32)])
+def test_bf16_pooled_activation_variants_match_the_fp32_kernels_on_the_stored_values(n, hc, wc, c):
+    """precision="bf16" stores the pooled activation p of blocks 2 and 3 as bf16. The p16 pool kernel must store exactly
+    bf16(max), keep the argmax, and take its statistics from the stored values; every consumer fed the bf16 tensor must
+    equal, bit for bit, its fp32 form fed p.float()."""
+    g = torch.Generator().manual_seed(93)
+    hp, wp = hc - 2, wc - 2
+    y = (torch.rand(n, hc, wc, c, generator=g) - 0.3).to(DEV)
+    parts = ops.stat_parts(8 * n)
+    p32 = torch.empty(n, hp, wp, c, device=DEV); i32 = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=DEV)
+    s32 = torch.empty(parts * 2 * c, dtype=torch.float64, device=DEV)
+    ops.pool_bnstats_fwd(y, p32, i32, s32, n, hc, wc, c)
+    p16 = torch.empty(n, hp, wp, c, dtype=torch.bfloat16, device=DEV); i16 = torch.empty_like(i32)
+    s16 = torch.empty_like(s32)
+    ops.pool_bnstats_fwd(y, p16, i16, s16, n, hc, wc, c)
+    assert torch.equal(p16, p32.to(torch.bfloat16)) and torch.equal(i16, i32)
+    pf = p16.float()
+    tot = s16.view(parts, 2, c).sum(0).cpu()
+    ref_sum, ref_sq = pf.double().sum((0, 1, 2)).cpu(), (pf.double() ** 2).sum((0, 1, 2)).cpu()
+    assert torch.allclose(tot[0], ref_sum, rtol=1e-12, atol=1e-9) and torch.allclose(tot[1], ref_sq, rtol=1e-12, atol=1e-9)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV); beta = (torch.rand(c, generator=g) - 0.5).to(DEV)
+    st = torch.empty(4, c, device=DEV)
+    ops.bn_finalize(s16, gamma, beta, None, None, 0.1, 1e-5, n * hp * wp, c, st[0], st[1], st[2], st[3])
+    # BatchNorm apply (flat and zero-padded forms)
+    a = ops.bn_apply_bf16(p16, st[2], st[3], torch.empty(n, hp, wp, c, dtype=torch.bfloat16, device=DEV), c)
+    b = ops.bn_apply_bf16(pf, st[2], st[3], torch.empty(n, hp, wp, c, dtype=torch.bfloat16, device=DEV), c)
+    assert torch.equal(a, b)
+    ba, va = ops.padded_bf16_alloc(n, hp, wp, c, DEV); bb, vb = ops.padded_bf16_alloc(n, hp, wp, c, DEV)
+    ops.to_bf16_padded(p16, st[2], st[3], va, n, hp, wp, c)
+    ops.to_bf16_padded(pf, st[2], st[3], vb, n, hp, wp, c)
+    assert torch.equal(ba, bb)
+    # backward passes, dz fp32 and bf16
+    npix = n * hp * wp
+    for dzt in (torch.float32, torch.bfloat16):
+        dz = (torch.rand(n, hp, wp, c, generator=g) - 0.5).to(torch.bfloat16).to(DEV).to(dzt)
+        out = {}
+        for name, pp in (("f32", pf), ("b16", p16)):
+            red = torch.empty(ops.stat_parts(max(npix // 64, 1)) * 2 * c, dtype=torch.float64, device=DEV)
+            ops.bn_bwd_reduce(dz, pp, st[0], st[1], red, npix, c)
+            coef3 = torch.empty(3 * c, device=DEV); dg = torch.empty(c, device=DEV); db = torch.empty(c, device=DEV)
+            ops.bn_bwd_finalize(red, gamma, st[0], st[1], npix, c, dg, db, coef3)
+            buf, dyp = ops.padded_bf16_alloc(n, hc, wc, c, DEV)
+            dparts = torch.empty(parts * c, dtype=torch.float64, device=DEV)
+            dy = torch.empty(n, hc, wc, c, device=DEV)
+            ops.bnpool_bwd_bf16p(dz, pp, i16, coef3, dy, dyp, dparts, n, hc, wc, c)
+            out[name] = (red.clone(), coef3, dy, buf.clone(), dparts)
+        for u, v in zip(out["f32"], out["b16"]):
+            assert torch.equal(u, v)
