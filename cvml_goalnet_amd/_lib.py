@@ -37,7 +37,7 @@ PROTOTYPES = {
     "goalnet_conv1_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "goalnet_stat_parts": (c_int, [c_int64]),
     "goalnet_pool_bnstats_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_pool_bnstats_fwd_p16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_pool_bnstats_fwd_p16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bn_finalize": (c_int, [P, c_int, P, P, P, P, c_float, c_float, c_int64, c_int, P, P, P, P, P]),
     "goalnet_bn_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P]),
     "goalnet_bn_bwd_reduce_t": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int64, c_int, P]),
@@ -69,7 +69,7 @@ PROTOTYPES = {
     "goalnet_linear_bwd_dx_bf16_o16_ok": (c_int, [c_int, c_int64, c_int]),
     "goalnet_linear_bwd_dx_bf16_o16": (c_int, [P, c_int64, P, P, c_int64, c_int, c_int64, c_int, P]),
     "goalnet_conv3x3_fwd_bf16p_o16_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_fwd_bf16p_o16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_fwd_bf16p_o16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_linear_bwd_dw_bf16": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int64, c_int, P]),
     "goalnet_linear_fwd_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "goalnet_linear_fwd": (c_int, [P, c_int64, P, P, c_int, P, P, c_int, P, c_int64, P, c_int64, P, c_int64,

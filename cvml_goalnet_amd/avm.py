@@ -392,11 +392,16 @@ class AVM(nn.Module):
         ops.partials_sum_f64(partials, width, row)
         return self.stat_sync.all_reduce(row)
 
+    @staticmethod
+    def _p16_ok(wc, c):
+        """shapes goalnet_pool_bnstats_fwd_p16 serves (32-channel slices, three conv rows in 64 KB of LDS)"""
+        return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536
+
     def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
         """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift).
         p16: the pooled activation is stored as bf16 (precision="bf16", blocks whose every consumer is a bf16 GEMM pass)."""
         dev = self._device
-        p16 = p16 and c % 32 == 0 and 3 * wc * 32 * 4 <= 65536          # what goalnet_pool_bnstats_fwd_p16 serves
+        assert p16 or y.dtype == F32
         p = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.bfloat16 if p16 else F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
         # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
@@ -439,32 +444,39 @@ class AVM(nn.Module):
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
         del y1          # the conv output is only an input of the pool: backward reads the ReLU mask off p (csrc/pool_bn.hip)
-        y2 = torch.empty(n, hp1, wp1, 256, dtype=F32, device=dev)
         bf = self.precision == "bf16"
         BF16 = torch.bfloat16
+        # where p is kept in bf16 AND the 256 x 256 tile computes the convolution, the conv output is stored as bf16 too:
+        # rounding is monotonic, so the max-pool of the rounded values is the rounded max-pool (same p, same statistics);
+        # only ties in the argmax are broken differently
+        p16_2 = bf and self.act_bf16 and self._p16_ok(wp1, 256)
+        y16_2 = p16_2 and ops.conv3x3_fwd_bf16p_o16_ok(n, hp1, wp1, 64, 256)
+        y2 = torch.empty(n, hp1, wp1, 256, dtype=BF16 if y16_2 else F32, device=dev)
         if bf:
             xh1 = ops.to_bf16_padded(p1, st1[2], st1[3], self._padbuf("x1" if save else "x1e", n, hp1, wp1, 64), n, hp1, wp1, 64)
             w2b = ops.cast_bf16(P("visbl.conv2.weight"), torch.empty(256 * 9 * 64, dtype=BF16, device=dev))
-            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16p,
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16p_o16 if y16_2 else ops.conv3x3_fwd_bf16p,
                         xh1, w2b, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
-        p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save, p16=bf and self.act_bf16)
+        p2, idx2, st2 = self._bn_block(y2, n, hp1, wp1, 256, 2, save, p16=p16_2)
         del y2
-        y3 = torch.empty(n, hp2, wp2, 512, dtype=F32, device=dev)
+        # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
+        # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
+        bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
+        p16_3 = bf5 and self.act_bf16 and self._p16_ok(wp2, 512)
+        y16_3 = p16_3 and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 256, 512)
+        y3 = torch.empty(n, hp2, wp2, 512, dtype=BF16 if y16_3 else F32, device=dev)
         if bf:
             xh2 = ops.to_bf16_padded(p2, st2[2], st2[3], self._padbuf("x2" if save else "x2e", n, hp2, wp2, 256), n, hp2, wp2, 256)
             w3b = ops.cast_bf16(P("visbl.conv3.weight"), torch.empty(512 * 9 * 256, dtype=BF16, device=dev))
-            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16p,
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16p_o16 if y16_3 else ops.conv3x3_fwd_bf16p,
                         xh2, w3b, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
         else:
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
-        # <= 16 rows: linear5 is a pure weight stream; the fp32 weight-streaming kernels (csrc/skinny.hip) read the
-        # arena once, which is cheaper (and exact) compared with casting 4 K J bytes to bf16 first
-        bf5 = bf and (n > 16 or os.environ.get("GOALNET_FORCE_BF5") == "1")
-        p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save, p16=bf5 and self.act_bf16)
+        p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save, p16=p16_3)
         del y3
 
         fw = 640 if self.audio_included else 512
@@ -630,7 +642,7 @@ class AVM(nn.Module):
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
             if o16_2:
                 self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p_o16,
-                            dyp3, wtb, dbn2, n, hp2, wp2, 512, 256)
+                            dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
             else:
                 self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
                             dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)

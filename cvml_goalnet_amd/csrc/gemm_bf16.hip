@@ -713,19 +713,19 @@ int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout) {
     return conv_use_256((int64_t)N * H * W, Cout) ? 1 : 0;
 }
 
-/* y_bf16[N][H][W][Cout] = bf16(conv3x3(x_pad, w)): no bias, no ReLU — the data-gradient use (w = flipped weights); the
- * fp32 accumulator is rounded once, at the store */
-int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, void* y_bf16, int N, int H, int W, int Cin, int Cout,
-                                  void* stream) {
+/* y_bf16[N][H][W][Cout] = bf16(act(conv3x3(x_pad, w) + bias)): the fp32 accumulator (+ bias, ReLU) is rounded once, at
+ * the store. bias NULL, relu 0: the data-gradient use (w = flipped weights). */
+int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const float* bias, int relu, void* y_bf16,
+                                  int N, int H, int W, int Cin, int Cout, void* stream) {
     GN_REQUIRE(x_pad && w_bf16 && y_bf16, GOALNET_E_NULL, "conv3x3_fwd_bf16p_o16: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: non-positive dim");
     GN_REQUIRE(Cin % BKH == 0 && Cout % 8 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: Cin %% 64, Cout %% 8");
-    GN_REQUIRE(aligned16(x_pad) && aligned16(w_bf16) && aligned16(y_bf16), GOALNET_E_ALIGN, "conv3x3_fwd_bf16p_o16: alignment");
+    GN_REQUIRE(aligned16(x_pad) && aligned16(w_bf16) && aligned16(y_bf16) && aligned16(bias), GOALNET_E_ALIGN, "conv3x3_fwd_bf16p_o16: alignment");
     const int64_t M = (int64_t)N * H * W;
     GN_REQUIRE((int64_t)N * (H + 2) * (W + 2) < (1ll << 31) - 4096, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: too many pixels");
     GN_REQUIRE(goalnet_conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout), GOALNET_E_SHAPE,
                "conv3x3_fwd_bf16p_o16: dims not served (ask goalnet_conv3x3_fwd_bf16p_o16_ok; use goalnet_conv3x3_fwd_bf16p)");
-    const EpiP ep{EPI_BIAS_RELU, nullptr, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, 0, y_bf16};
+    const EpiP ep{EPI_BIAS_RELU, nullptr, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0, y_bf16};
     return launch_conv_bf16_256("conv3x3_fwd_bf16p_o16(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M, (const __hip_bfloat16*)w_bf16,
                                 Cout, ep, (hipStream_t)stream);
 }

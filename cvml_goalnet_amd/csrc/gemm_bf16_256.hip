@@ -378,8 +378,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
     const int r4 = r & ~3;
-    if constexpr (ROLE == 1 || ROLE == 4) {
-        // bf16 result (the gradient wrt a BatchNorm output, consumed by two HBM-bound passes): after the quad transpose
+    if constexpr (ROLE == 0 || ROLE == 1 || ROLE == 4) {
+        // bf16 result (a conv output on its way to the max-pool, or the gradient wrt a BatchNorm output; both are only read
+        // by HBM-bound passes): after the quad transpose
         // lanes l and l ^ 4 hold columns c..c+3 and c+4..c+7 of the same rows for two register groups (rows 8 apart);
         // they swap one packed group so that each stores 8 consecutive bf16 (16 B) of ONE row: 16 store instructions
         // per wave for the tile (the fp32 form needs 32) and half the bytes.
@@ -393,6 +394,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                     const int col4 = tn * T + (TRB ? ni * 128 + 16 * wc + (r4 & 15) + 64 * (r4 >> 4) : wc * 64 + ni * 32 + r4);
                     const int col8 = col4 - 4 * hi;                                                    // first of this lane's 8 columns
                     const bool colok = col8 < ep.cols;                                                 // cols % 8 == 0
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (brelu && ep.bias && colok) bv = *reinterpret_cast<const float4*>(ep.bias + col4);
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         unsigned pk[2][2];
@@ -401,7 +404,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                             const int g = 2 * gp + k;
                             float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
                             quad_transpose4(n0, n1, n2, n3, lane);
-                            pk[k][0] = pack2_bf16(n0, n1); pk[k][1] = pack2_bf16(n2, n3);
+                            pk[k][0] = pack2_bf16(fmaxf(n0 + bv.x, lo), fmaxf(n1 + bv.y, lo));
+                            pk[k][1] = pack2_bf16(fmaxf(n2 + bv.z, lo), fmaxf(n3 + bv.w, lo));
                         }
                         // lane hi = 0 keeps group 2gp and gets the partner's 2gp (its columns + 4); hi = 1 keeps 2gp + 1
                         const unsigned s0 = hi ? pk[0][0] : pk[1][0], s1 = hi ? pk[0][1] : pk[1][1];

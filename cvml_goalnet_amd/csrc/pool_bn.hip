@@ -308,8 +308,9 @@ __device__ __forceinline__ float4 load_p4(const __hip_bfloat16* q) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
-template <typename PT>
-__global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* __restrict__ y, PT* __restrict__ p,
+// NPW = passes of 32 pixels per conv row (launcher: ceil(Wc / 32) <= 6)
+template <typename YT, typename PT, int NPW>
+__global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const YT* __restrict__ y, PT* __restrict__ p,
                                                                  uint8_t* __restrict__ idx, double* __restrict__ partials,
                                                                  int N, int Hc, int Wc, int C, int bands) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][Wc][CS] floats (>= 16 KB for the reduction)
@@ -323,19 +324,35 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const float* _
     for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {
         const int n = unit / bands, band = unit % bands;
         const int p0 = (int)((int64_t)Hp * band / bands), p1 = (int)((int64_t)Hp * (band + 1) / bands);
-        const float* yn = y + (int64_t)n * Hc * Wc * C + c0;
+        const YT* yn = y + (int64_t)n * Hc * Wc * C + c0;
         PT* pn = p + (int64_t)n * Hp * Wp * C + c0;
         uint8_t* in = idx ? idx + ((int64_t)n * ccn + blockIdx.x % ccn) * Hp * Wp * CS + l8 * 4 : nullptr;     // slice-major, see idx_off
+        // Software pipeline over conv rows, as in the backward kernel below: the loads of row r+1 are issued (unconditionally,
+        // from clamped addresses, raw) before row r's windows are computed and are written to the LDS ring one iteration later.
+        // Loading straight into LDS paid one global round trip per row between two barriers (2.7 TB/s with a bf16 y).
+        decltype(load_dz4_raw(yn)) ry[NPW];
+        auto fetch = [&](int rr) {
+            const int rc = rr < Hc ? rr : Hc - 1;
+#pragma unroll
+            for (int ps = 0; ps < NPW; ++ps) {
+                const int x = px + 32 * ps, xc = x < Wc ? x : Wc - 1;
+                ry[ps] = load_dz4_raw(yn + ((int64_t)rc * Wc + xc) * C);
+            }
+        };
+        auto stash = [&](int rr) {
+#pragma unroll
+            for (int ps = 0; ps < NPW; ++ps) {
+                const int x = px + 32 * ps;
+                if (x < Wc) *reinterpret_cast<float4*>(&smem[(((rr % 3) * Wc) + x) * CS + l8 * 4]) = dz4_of(ry[ps]);
+            }
+        };
         __syncthreads();
-        for (int rr = p0; rr < p0 + 2; ++rr)
-            for (int x = px; x < Wc; x += 32)
-                *reinterpret_cast<float4*>(&smem[(((rr % 3) * Wc) + x) * CS + l8 * 4]) =
-                    *reinterpret_cast<const float4*>(yn + ((int64_t)rr * Wc + x) * C);
+        fetch(p0); stash(p0);
+        fetch(p0 + 1); stash(p0 + 1);
+        fetch(p0 + 2);
         for (int ph = p0; ph < p1; ++ph) {
-            const int rnew = ph + 2;
-            for (int x = px; x < Wc; x += 32)
-                *reinterpret_cast<float4*>(&smem[(((rnew % 3) * Wc) + x) * CS + l8 * 4]) =
-                    *reinterpret_cast<const float4*>(yn + ((int64_t)rnew * Wc + x) * C);
+            stash(ph + 2);
+            fetch(ph + 3);
             __syncthreads();
             for (int pw = px; pw < Wp; pw += 32) {
                 float4 best;
@@ -500,6 +517,20 @@ int row_bands(int nparts, int N, int rows) {
     return b < 1 ? 1 : b;
 }
 
+template <typename YT, typename PT>
+static void launch_pool_fwd_v2(int nparts, size_t lds, hipStream_t st, const YT* y, PT* p, uint8_t* idx, double* partials, int N, int Hc, int Wc, int C) {
+    const dim3 grid(nparts * (C / CS)), block(256);
+    const int bands = row_bands(nparts, N, Hc - 2);
+    switch ((Wc + 31) / 32) {                                    // passes of 32 pixels per conv row; the LDS limit keeps Wc <= 170
+    case 1: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 1>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    case 2: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 2>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    case 3: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 3>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    case 4: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 4>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    case 5: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 5>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    default: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 6>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
+    }
+}
+
 template <typename DZ, typename PT>
 static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const PT* p, const uint8_t* idx, const float* coef3,
                                  float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
@@ -535,8 +566,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
-        hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel<float>, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y, p, idx,
-                           partials, N, Hc, Wc, C, row_bands(nparts, N, Hc - 2));
+        launch_pool_fwd_v2<float, float>(nparts, need, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     }
@@ -544,7 +574,9 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
     return 0;
 }
 
-int goalnet_pool_bnstats_fwd_p16(const float* y, void* p_bf16, uint8_t* idx, double* partials, int nparts,
+/* p stored as bf16; y fp32 (y_bf16 = 0) or bf16 as goalnet_conv3x3_fwd_bf16p_o16 writes it (rounding is monotonic: the
+ * maximum of the rounded values is the rounded maximum, so p is the same either way; only ties in the argmax differ) */
+int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_t* idx, double* partials, int nparts,
                                  int N, int Hc, int Wc, int C, void* stream) {
     GN_REQUIRE(y && p_bf16 && partials, GOALNET_E_NULL, "pool_bnstats_fwd_p16: null pointer");
     GN_PARTS_OK("pool_bnstats_fwd_p16");
@@ -555,8 +587,9 @@ int goalnet_pool_bnstats_fwd_p16(const float* y, void* p_bf16, uint8_t* idx, dou
     const size_t lds = (size_t)3 * Wc * CS * sizeof(float);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: image too wide for the rolling LDS rows");
     const size_t need = lds < 16384 ? 16384 : lds;
-    hipLaunchKernelGGL(pool_bnstats_fwd_v2_kernel<__hip_bfloat16>, dim3(nparts * (C / CS)), dim3(256), need, (hipStream_t)stream, y,
-                       (__hip_bfloat16*)p_bf16, idx, partials, N, Hc, Wc, C, row_bands(nparts, N, Hc - 2));
+    typedef __hip_bfloat16 bf;
+    if (y_bf16) launch_pool_fwd_v2<bf, bf>(nparts, need, (hipStream_t)stream, (const bf*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);
+    else launch_pool_fwd_v2<float, bf>(nparts, need, (hipStream_t)stream, (const float*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("pool_bnstats_fwd_p16");
     return 0;
 }

@@ -117,9 +117,10 @@ def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
     assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
     if p.dtype == torch.bfloat16:                   # pooled activation stored as bf16 (statistics of the stored values)
-        check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
-                                                 N, Hc, Wc, C, _s()), "pool_bnstats_fwd_p16")
+        check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), int(y.dtype == torch.bfloat16), p.data_ptr(), _p(idx), partials.data_ptr(),
+                                                 _rows(partials, 2 * C), N, Hc, Wc, C, _s()), "pool_bnstats_fwd_p16")
         return
+    assert y.dtype == F32
     check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
                                          N, Hc, Wc, C, _s()), "pool_bnstats_fwd")
 
@@ -279,12 +280,13 @@ def conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout) -> bool:
     return bool(lib().goalnet_conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout))
 
 
-def conv3x3_fwd_bf16p_o16(xpad, w, y, N, H, W, Cin, Cout):
-    """bf16 result, no bias / ReLU (data gradient); only for dims conv3x3_fwd_bf16p_o16_ok accepts"""
-    _chk(xpad, w, y)
+def conv3x3_fwd_bf16p_o16(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
+    """bf16 result (bias None, relu False: the data gradient); only for dims conv3x3_fwd_bf16p_o16_ok accepts"""
+    _chk(xpad, w, bias, y)
     assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == BF16
     assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
-    check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), y.data_ptr(), N, H, W, Cin, Cout, _s()), "conv3x3_fwd_bf16p_o16")
+    check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
+          "conv3x3_fwd_bf16p_o16")
     return y
 
 

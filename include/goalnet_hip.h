@@ -75,8 +75,9 @@ int goalnet_conv1_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw_ohw
 int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* partials, int nparts,
                              int N, int Hc, int Wc, int C, void* stream);
 /* The same with the pooled activation stored as bf16 (C % 32 == 0): precision = "bf16" keeps p of blocks 2 and 3 in bf16 — it is
- * read three more times per step and every GEMM behind it consumes bf16. The statistics are those of the values as stored. */
-int goalnet_pool_bnstats_fwd_p16(const float* y, void* p_bf16, uint8_t* idx, double* partials, int nparts,
+ * read three more times per step and every GEMM behind it consumes bf16. The statistics are those of the values as stored.
+ * y: fp32 (y_bf16 = 0) or bf16 (1, from goalnet_conv3x3_fwd_bf16p_o16): rounding is monotonic, so p is the same either way. */
+int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_t* idx, double* partials, int nparts,
                                  int N, int Hc, int Wc, int C, void* stream);
 /* mean/biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated
  * with `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
@@ -159,13 +160,14 @@ int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const flo
 size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout);   /* split-K slabs, as goalnet_conv3x3_fwd */
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* The same convolution with its result stored as bf16 [N][H][W][Cout], no bias / ReLU: the data-gradient use (w = flipped
- * weights), whose result — the gradient wrt a BatchNorm output — is only read by two HBM-bound passes
- * (goalnet_bn_bwd_reduce_dz16, goalnet_bnpool_bwd_bf16p_dz16). fp32 accumulation, one rounding at the store. Served by the
+/* The same convolution with its result stored as bf16 [N][H][W][Cout] (bias, relu as above; both off = the data-gradient use
+ * with w = flipped weights). Its consumers are HBM-bound passes only: the max-pool of the forward
+ * (goalnet_pool_bnstats_fwd_p16) and the BatchNorm backward (goalnet_bn_bwd_reduce_t, goalnet_bnpool_bwd_bf16p_t).
+ * fp32 accumulation, one rounding at the store. Served by the
  * 256 x 256 tile only: goalnet_conv3x3_fwd_bf16p_o16_ok() says whether the dims are; otherwise use the fp32-output form. */
 int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout);
-int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, void* y_bf16, int N, int H, int W, int Cin, int Cout,
-                                  void* stream);
+int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const float* bias, int relu, void* y_bf16,
+                                  int N, int H, int W, int Cin, int Cout, void* stream);
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
                                int N, int H, int W, int Cin, int Cout, void* stream);

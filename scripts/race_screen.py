@@ -47,7 +47,7 @@ for n, h, w, cin, cout in ((49, 72, 72, 256, 512), (25, 74, 74, 64, 256), (13, 7
     screen(f"conv fwd   {n}x{h}x{w} {cin}->{cout}", lambda: ops.conv3x3_fwd_bf16p(xp, wt, b, True, y, n, h, w, cin, cout), y)
     if cout % 8 == 0:
         y16 = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=dev)
-        screen(f"conv fwd (bf16 out) {n}x{h}x{w} {cin}->{cout}", lambda: ops.conv3x3_fwd_bf16p_o16(xp, wt, y16, n, h, w, cin, cout), y16)
+        screen(f"conv fwd (bf16 out) {n}x{h}x{w} {cin}->{cout}", lambda: ops.conv3x3_fwd_bf16p_o16(xp, wt, b, True, y16, n, h, w, cin, cout), y16)
 for m, j, k in ((320, 512, (1 << 18) + 264), (1024, 512, 1 << 19), (96, 128, 70000)):
     dyl = (torch.rand(m, j, generator=g) - 0.5).to(torch.bfloat16).to(dev)
     xl = (torch.rand(m, k, generator=g) - 0.5).to(torch.bfloat16).to(dev)

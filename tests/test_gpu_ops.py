@@ -550,8 +550,13 @@ def test_bf16_gradient_outputs_equal_the_fp32_outputs_rounded_once(tile, monkeyp
     _, xp = _padded(x)
     assert ops.conv3x3_fwd_bf16p_o16_ok(n, h, wd, cin, cout)
     f32 = ops.conv3x3_fwd_bf16p(xp, wt, None, False, torch.empty(n, h, wd, cout, device=DEV), n, h, wd, cin, cout)
-    b16 = ops.conv3x3_fwd_bf16p_o16(xp, wt, torch.full((n, h, wd, cout), float("nan"), dtype=torch.bfloat16, device=DEV), n, h, wd, cin, cout)
+    b16 = ops.conv3x3_fwd_bf16p_o16(xp, wt, None, False, torch.full((n, h, wd, cout), float("nan"), dtype=torch.bfloat16, device=DEV), n, h, wd, cin, cout)
     assert torch.equal(b16, f32.to(torch.bfloat16))
+    # forward form: bias + ReLU, then one rounding
+    bias = (torch.rand(cout, generator=g) - 0.5).to(DEV)
+    f32 = ops.conv3x3_fwd_bf16p(xp, wt, bias, True, torch.empty(n, h, wd, cout, device=DEV), n, h, wd, cin, cout)
+    b16 = ops.conv3x3_fwd_bf16p_o16(xp, wt, bias, True, torch.full((n, h, wd, cout), float("nan"), dtype=torch.bfloat16, device=DEV), n, h, wd, cin, cout)
+    assert torch.equal(b16, f32.to(torch.bfloat16)) and (b16 == 0).any() and (b16 > 0).any()
     monkeypatch.setenv("GOALNET_BF16_TILE", "128")                       # the 128 x 128 kernels have no bf16 epilogue: must refuse
     assert not ops.linear_bwd_dx_bf16_o16_ok(m, k, j) and not ops.conv3x3_fwd_bf16p_o16_ok(n, h, wd, cin, cout)
     with pytest.raises(Exception):
@@ -608,6 +613,17 @@ def test_bf16_pooled_activation_variants_match_the_fp32_kernels_on_the_stored_va
     s16 = torch.empty_like(s32)
     ops.pool_bnstats_fwd(y, p16, i16, s16, n, hc, wc, c)
     assert torch.equal(p16, p32.to(torch.bfloat16)) and torch.equal(i16, i32)
+    # a bf16 conv output: rounding is monotonic, so p and the statistics are identical; the argmax may move only between
+    # window elements that are equal after rounding
+    yb = y.to(torch.bfloat16)
+    pb = torch.empty_like(p16); ib = torch.empty_like(i32); sb = torch.empty_like(s32)
+    ops.pool_bnstats_fwd(yb, pb, ib, sb, n, hc, wc, c)
+    assert torch.equal(pb, p16) and torch.equal(sb, s16)
+    moved = ops.idx_to_nhwc(ib, n, hp, wp, c) != ops.idx_to_nhwc(i16, n, hp, wp, c)
+    if moved.any():
+        win = yb.float().unfold(1, 3, 1).unfold(2, 3, 1).permute(0, 1, 2, 4, 5, 3).reshape(n, hp, wp, 9, c)   # [.., tap, c]
+        tb = torch.gather(win, 3, ops.idx_to_nhwc(ib, n, hp, wp, c).long().unsqueeze(3)).squeeze(3)
+        assert torch.equal(tb, pb.float()), "the argmax of a bf16 conv output must point at an element equal to the maximum"
     pf = p16.float()
     tot = s16.view(parts, 2, c).sum(0).cpu()
     ref_sum, ref_sq = pf.double().sum((0, 1, 2)).cpu(), (pf.double() ** 2).sum((0, 1, 2)).cpu()
