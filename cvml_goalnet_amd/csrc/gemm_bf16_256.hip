@@ -262,6 +262,15 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
     }                                                                                                       \
     asm volatile("s_setprio 0\n\ts_barrier" ::: "memory");
 
+#ifdef GN_STAMPS
+// Diagnostic build only (-DGN_STAMPS, loaded through GOALNET_LIB_PATH by scripts/ablate_conv.py): wave 0 of every block
+// stamps the 100 MHz real-time counter at six points; the stamps go to a buffer nothing else reads.
+__device__ unsigned long long gn_stamps[6 * 65536];
+#define GN_STAMP(I) if (tid == 0 && blockIdx.x < 65536) gn_stamps[6 * blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GN_STAMP(I)
+#endif
+
 // ROLE only separates the symbols (0: convolution forward, 1: data gradient) so that profiles list them apart
 template <class AL, class BL, int ROLE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
@@ -271,6 +280,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
     int tm, tn, split = 0;
+    GN_STAMP(0)
     if (ROLE == 2 || ROLE == 3) {
         // weight gradient (and the linear5 forward): few output tiles (18 / 8), many K splits. All tiles of a split read the same pixels, so they run on
         // ONE XCD back to back (blocks L, L + 8, ... share an XCD): XCD x takes splits x, x + 8, ... and walks their tiles.
@@ -289,20 +299,31 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     const int kt0 = split * ktiles_per_split;                           // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
     const int ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
 
+    // The accumulators start at the bias (convolution forward: all 16 registers of acc[.][j] are one output column), so the
+    // epilogue has no add left: it is instruction-bound (in-kernel stamps: 6.5 - 9.7 us of a 68 - 72 us tile; ~1100 VALU
+    // instructions per wave, of which the transposes are half and bias + clamp were a quarter).
     f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 2; ++j) {
+        float b0 = 0.f;
+        if constexpr (ROLE == 0) {
+            const int colj = tn * T + wc * 64 + j * 32 + (lane & 31);
+            if (ep.bias && colj < ep.cols) b0 = ep.bias[colj];
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = b0;
+    }
 
     auto slot = [&](int t, int s) -> char* { return lds + ((t & 1) * 4 + s) * HALF_BYTES; };     // s: 0 A0, 1 A1, 2 B0, 3 B1
 
     // prologue: K-tile 0 complete, K-tile 1 without its A1 (phase (0,q0) stages that)
     al.issue(kt0 + 0, 0, slot(0, 0)); bl.issue(kt0 + 0, 0, slot(0, 2)); bl.issue(kt0 + 0, 1, slot(0, 3)); al.issue(kt0 + 0, 1, slot(0, 1));
     bl.issue(kt0 + 1, 0, slot(1, 2)); al.issue(kt0 + 1, 0, slot(1, 0)); bl.issue(kt0 + 1, 1, slot(1, 3));
+    GN_STAMP(1)
     asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    GN_STAMP(2)
     if (wr == 1) asm volatile("s_barrier" ::: "memory");                 // stagger the two wave rows by one barrier
 
     // fragment registers: a = the current A half; bx / by = B0 / B1 of even K-tiles and B1 / B0 of odd ones: the B0
@@ -361,6 +382,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
         GN_KTILE(t, bx, by);
         if (t + 1 < ktiles) GN_KTILE(t + 1, by, bx);
     }
+    GN_STAMP(3)
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
     // drain: no DMA may land after the block has released its LDS, and the last MFMAs (16 passes) must have written back
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -369,14 +391,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));                    // no DMA may land after the block has released its LDS
 
+    GN_STAMP(4)
     // epilogue (conv forward: bias + ReLU; data gradient: raw; weight gradient / linear5 forward: raw split-K slab).
     // A lane of the 32x32 accumulator holds 4 consecutive ROWS of one column per register group; quad_transpose4
     // (gemm_common.h) turns that into 4 consecutive COLUMNS of one row, i.e. one 16-byte store per lane and whole 128-B lines
     // per quad row: 32 store instructions per wave instead of 128 (the tail of a 256 x 256 fp32 tile is store-issue-bound).
     const int r = lane & 31, hh = lane >> 5;
-    const bool brelu = ep.mode == EPI_BIAS_RELU && ep.slab_stride == 0;
+    // what is left to do per value: ROLE 0 (conv forward) clamps at 0 when ReLU is on (its bias is already in); the
+    // other roles store the accumulator as it is (their callers pass no bias and no ReLU)
+    auto fin = [&](float v) -> float {
+        if constexpr (ROLE == 0) return ep.relu ? fmaxf(v, 0.f) : v;
+        else return v;
+    };
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
-    const float lo = (brelu && ep.relu) ? 0.f : -INFINITY;
     const int r4 = r & ~3;
     if constexpr (ROLE == 0 || ROLE == 1 || ROLE == 4) {
         // bf16 result (a conv output on its way to the max-pool, or the gradient wrt a BatchNorm output; both are only read
@@ -394,8 +421,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                     const int col4 = tn * T + (TRB ? ni * 128 + 16 * wc + (r4 & 15) + 64 * (r4 >> 4) : wc * 64 + ni * 32 + r4);
                     const int col8 = col4 - 4 * hi;                                                    // first of this lane's 8 columns
                     const bool colok = col8 < ep.cols;                                                 // cols % 8 == 0
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (brelu && ep.bias && colok) bv = *reinterpret_cast<const float4*>(ep.bias + col4);
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         unsigned pk[2][2];
@@ -404,8 +429,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                             const int g = 2 * gp + k;
                             float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
                             quad_transpose4(n0, n1, n2, n3, lane);
-                            pk[k][0] = pack2_bf16(fmaxf(n0 + bv.x, lo), fmaxf(n1 + bv.y, lo));
-                            pk[k][1] = pack2_bf16(fmaxf(n2 + bv.z, lo), fmaxf(n3 + bv.w, lo));
+                            pk[k][0] = pack2_bf16(fin(n0), fin(n1));
+                            pk[k][1] = pack2_bf16(fin(n2), fin(n3));
                         }
                         // lane hi = 0 keeps group 2gp and gets the partner's 2gp (its columns + 4); hi = 1 keeps 2gp + 1
                         const unsigned s0 = hi ? pk[0][0] : pk[1][0], s1 = hi ? pk[0][1] : pk[1][1];
@@ -418,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                             *reinterpret_cast<uint4*>(o16 + row * ep.ld + col8) = hi ? make_uint4(q0, q1, m0, m1) : make_uint4(m0, m1, q0, q1);
                     }
                 }
+            GN_STAMP(5)
             return;
         }
     }
@@ -427,8 +453,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
         for (int ni = 0; ni < 2; ++ni) {
             const int col = tn * T + (TRB ? ni * 128 + 16 * wc + (r4 & 15) + 64 * (r4 >> 4) : wc * 64 + ni * 32 + r4);   // first of 4 columns
             const bool colok = col < ep.cols;                                                                          // cols % 4 == 0
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (brelu && ep.bias && colok) bv = *reinterpret_cast<const float4*>(ep.bias + col);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
@@ -438,12 +462,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                                                            : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + i);
                 if (colok && row < ep.rows)
                     *reinterpret_cast<float4*>(outp + row * ep.ld + col) =
-                        make_float4(fmaxf(n0 + bv.x, lo), fmaxf(n1 + bv.y, lo), fmaxf(n2 + bv.z, lo), fmaxf(n3 + bv.w, lo));
+                        make_float4(fin(n0), fin(n1), fin(n2), fin(n3));
             }
         }
+    GN_STAMP(5)
 }
 
 }  // namespace
+
+#ifdef GN_STAMPS
+extern "C" int goalnet_debug_stamps(unsigned long long* host_dst, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gn_stamps), sizeof(unsigned long long) * 6 * (size_t)nblocks);
+}
+#endif
 
 namespace goalnet {
 
@@ -472,7 +503,8 @@ static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_p
 // conv 3x3 forward (bias + ReLU epilogue) / data gradient (raw epilogue) on zero-padded bf16 activations, 256^2 phased tile
 int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
                          int Cout, const EpiP& ep, hipStream_t st) {
-    return ep.mode == EPI_BIAS_RELU && ep.relu ? launch_conv_bf16_256_role<0>(name, x_pad, H, W, Cin, M, w, Cout, ep, st)
+    // ROLE 0 carries the bias (in its accumulator start) and the optional ReLU; ROLE 1 stores raw accumulators
+    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_conv_bf16_256_role<0>(name, x_pad, H, W, Cin, M, w, Cout, ep, st)
                                                : launch_conv_bf16_256_role<1>(name, x_pad, H, W, Cin, M, w, Cout, ep, st);
 }
 
