@@ -102,18 +102,18 @@ __global__ __launch_bounds__(256) void conv1d_dx_big_kernel(const float* __restr
     }
 }
 
-// dW: block = 4 x 4 (co, ci) pairs x 16 frame lanes; every lane walks its frames (fp32 per frame, fp64 across frames), the 16
-// lane totals of a pair are added in a fixed order. The block re-uses each dz / x row 4 times from L1.
+// dW: block = one co x 4 ci x 64 frame lanes; every lane walks its frames (fp32 per frame, fp64 across frames), the 64 lane
+// totals of a pair are added in a fixed order. (With 16 frame lanes per pair a lane walked 64 frames at 1024: 0.42 ms.)
 __global__ __launch_bounds__(256) void conv1d_dw_big_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                            float* __restrict__ dw, int N, int Cin, int L, int Cout, int Lo,
                                                            int stride, int pad) {
-    __shared__ double red[16][16][3];
-    const int pair = threadIdx.x >> 4, lanef = threadIdx.x & 15;
+    __shared__ double red[4][64][3];
+    const int pair = threadIdx.x >> 6, lanef = threadIdx.x & 63;
     const int cig = (Cin + 3) / 4;
-    const int co = (blockIdx.x / cig) * 4 + (pair >> 2), ci = (blockIdx.x % cig) * 4 + (pair & 3);
+    const int co = blockIdx.x / cig, ci = (blockIdx.x % cig) * 4 + pair;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    if (co < Cout && ci < Cin) {
-        for (int n = lanef; n < N; n += 16) {
+    if (ci < Cin) {
+        for (int n = lanef; n < N; n += 64) {
             const float* xs = x + ((int64_t)n * Cin + ci) * L;
             const float* ds = dz + ((int64_t)n * Cout + co) * Lo;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -129,10 +129,10 @@ __global__ __launch_bounds__(256) void conv1d_dw_big_kernel(const float* __restr
     }
     red[pair][lanef][0] = a0; red[pair][lanef][1] = a1; red[pair][lanef][2] = a2;
     __syncthreads();
-    if (lanef < 3 && co < Cout && ci < Cin) {
+    if (lanef < 3 && ci < Cin) {
         double t = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[pair][j][lanef];
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) t += red[pair][j][lanef];
         dw[((int64_t)co * Cin + ci) * 3 + lanef] = (float)t;
     }
 }
@@ -256,19 +256,29 @@ __global__ __launch_bounds__(256) void head_bwd_dh_kernel(const float* __restric
     }
 }
 
-// dw[k] = sum_n dlogit[n] h[n][k]; db = sum_n dlogit[n].  Thread k (K <= 1024), plus thread K for db.
+// dw[k] = sum_n dlogit[n] h[n][k]; db = sum_n dlogit[n] (column K). Block = 64 columns x 16 row groups: a wave reads 64
+// consecutive k of one row, every thread sums its rows in fp64, the 16 group totals of a column are added in a fixed order.
+// (One thread per column walking all rows took 316 us at 1024 rows: a thousand dependent round trips.)
 __global__ __launch_bounds__(1024) void head_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                           const float* __restrict__ h, int64_t ldh, float* __restrict__ dw,
                                                           float* __restrict__ db, int N, int K) {
-    const int k = threadIdx.x;
-    if (k > K) return;
+    __shared__ double red[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
     double a = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float g = dlogit_of(dout[n], out[n]);
-        a += (double)(k < K ? g * h[(int64_t)n * ldh + k] : g);
-    }
-    if (k < K) dw[k] = (float)a;
-    else db[0] = (float)a;
+    if (k <= K)
+        for (int n = rg; n < N; n += 16) {
+            const float g = dlogit_of(dout[n], out[n]);
+            a += (double)(k < K ? g * h[(int64_t)n * ldh + k] : g);
+        }
+    red[rg][c] = a;
+    __syncthreads();
+    if (rg != 0 || k > K) return;
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][c];
+    if (k < K) dw[k] = (float)t;
+    else db[0] = (float)t;
 }
 
 // loss = 1/n^2 sum_i sum_j (p_i - y_j)^2 = mean_i (p_i^2 - 2 p_i ybar + mean(y^2)); dpred_i = 2/n (p_i - ybar)
@@ -388,7 +398,7 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
         GN_LAUNCH_CHECK("conv1d_bwd.dx");
     }
     if (many)
-        hipLaunchKernelGGL(conv1d_dw_big_kernel, dim3(((Cout + 3) / 4) * ((Cin + 3) / 4)), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
+        hipLaunchKernelGGL(conv1d_dw_big_kernel, dim3(Cout * ((Cin + 3) / 4)), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
     else
         hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
     GN_LAUNCH_CHECK("conv1d_bwd.dw");
@@ -439,8 +449,7 @@ int goalnet_head_bwd(const float* dout, const float* out, const float* h, int64_
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(head_bwd_dh_kernel, dim3(grid1d((int64_t)N * K)), dim3(256), 0, st, dout, out, w, mult, ldmult, dh, lddh, N, K);
     GN_LAUNCH_CHECK("head_bwd.dh");
-    const int threads = ((K + 1 + 63) / 64) * 64;
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(1), dim3(threads), 0, st, dout, out, h, ldh, dw, db, N, K);
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((K + 1 + 63) / 64), dim3(1024), 0, st, dout, out, h, ldh, dw, db, N, K);
     GN_LAUNCH_CHECK("head_bwd.dw");
     return 0;
 }
