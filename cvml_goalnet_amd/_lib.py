@@ -79,7 +79,8 @@ PROTOTYPES = {
     "goalnet_colsum": (c_int, [P, c_int64, c_int, c_int, P, P]),
     "goalnet_mul": (c_int, [P, c_int64, P, c_int64, P, c_int64, c_int, c_int, P]),
     "goalnet_conv1d_fwd": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_conv1d_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv1d_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "goalnet_conv1d_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "goalnet_relu_bwd": (c_int, [P, P, P, c_int64, P]),
     "goalnet_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, P]),
     "goalnet_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, P]),

@@ -105,15 +105,18 @@ __global__ __launch_bounds__(256) void conv1d_dx_big_kernel(const float* __restr
 // dW: block = 4 x 4 (co, ci) pairs x 16 frame lanes; every lane walks its frames (fp32 per frame, fp64 across frames), the 16
 // lane totals of a pair are added in a fixed order. The block re-uses each dz / x row 4 times from L1.
 __global__ __launch_bounds__(256) void conv1d_dw_big_kernel(const float* __restrict__ x, const float* __restrict__ dz,
-                                                           float* __restrict__ dw, int N, int Cin, int L, int Cout, int Lo,
-                                                           int stride, int pad) {
+                                                           float* __restrict__ dw, double* __restrict__ part, int N, int Cin, int L,
+                                                           int Cout, int Lo, int stride, int pad) {
     __shared__ double red[16][16][3];
     const int pair = threadIdx.x >> 4, lanef = threadIdx.x & 15;
     const int cig = (Cin + 3) / 4;
     const int co = (blockIdx.x / cig) * 4 + (pair >> 2), ci = (blockIdx.x % cig) * 4 + (pair & 3);
+    // blockIdx.y = slice of the frames (gridDim.y > 1: fp64 partial sums to `part`, added in slice order by
+    // conv1d_dw_sum_kernel; with one slice a lane walked N / 16 frames: 0.42 ms at 1024 frames for 0.2 GFLOP)
+    const int n0 = (int)((int64_t)N * blockIdx.y / gridDim.y), n1 = (int)((int64_t)N * (blockIdx.y + 1) / gridDim.y);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (co < Cout && ci < Cin) {
-        for (int n = lanef; n < N; n += 16) {
+        for (int n = n0 + lanef; n < n1; n += 16) {
             const float* xs = x + ((int64_t)n * Cin + ci) * L;
             const float* ds = dz + ((int64_t)n * Cout + co) * Lo;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -133,8 +136,18 @@ __global__ __launch_bounds__(256) void conv1d_dw_big_kernel(const float* __restr
         double t = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += red[pair][j][lanef];
-        dw[((int64_t)co * Cin + ci) * 3 + lanef] = (float)t;
+        const int64_t o = ((int64_t)co * Cin + ci) * 3 + lanef;
+        if (gridDim.y == 1) dw[o] = (float)t;
+        else part[(int64_t)blockIdx.y * Cout * Cin * 3 + o] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void conv1d_dw_sum_kernel(const double* __restrict__ part, int slices, int64_t n, float* __restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double t = 0.0;
+    for (int s = 0; s < slices; ++s) t += part[(int64_t)s * n + i];
+    dw[i] = (float)t;
 }
 
 // dw[co][ci][k] = sum_{n,lo} dz[n][co][lo] * x[n][ci][stride*lo - pad + k]; one block per (co, ci), the 256
@@ -383,8 +396,14 @@ int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu,
     return 0;
 }
 
+constexpr int CONV1D_DW_SLICES = 8;      // frame slices of the many-frame weight gradient
+
+size_t goalnet_conv1d_bwd_ws_bytes(int N, int Cin, int Cout) {
+    return N >= 64 * CONV1D_DW_SLICES ? (size_t)CONV1D_DW_SLICES * Cout * Cin * 3 * sizeof(double) : 0;
+}
+
 int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* dx, float* dw, float* db,
-                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream) {
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
     GN_REQUIRE(x && dz && w && dw && db, GOALNET_E_NULL, "conv1d_bwd: null pointer");
     GN_REQUIRE(N > 0 && Cin > 0 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE, "conv1d_bwd: bad dims");
     const int Lo = (L + 2 * pad - 3) / stride + 1;
@@ -397,9 +416,17 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
             hipLaunchKernelGGL(conv1d_dx_kernel, dim3(grid1d((int64_t)N * Cin * L * 16)), dim3(256), 0, st, dz, w, dx, N, Cin, L, Cout, Lo, stride, pad);
         GN_LAUNCH_CHECK("conv1d_bwd.dx");
     }
-    if (many)
-        hipLaunchKernelGGL(conv1d_dw_big_kernel, dim3(((Cout + 3) / 4) * ((Cin + 3) / 4)), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
-    else
+    if (many) {
+        const size_t need = goalnet_conv1d_bwd_ws_bytes(N, Cin, Cout);
+        const int slices = need && ws && ws_bytes >= need ? CONV1D_DW_SLICES : 1;
+        GN_REQUIRE(slices == 1 || (reinterpret_cast<uintptr_t>(ws) & 7u) == 0, GOALNET_E_ALIGN, "conv1d_bwd: workspace must be 8-byte aligned");
+        hipLaunchKernelGGL(conv1d_dw_big_kernel, dim3(((Cout + 3) / 4) * ((Cin + 3) / 4), slices), dim3(256), 0, st, x, dz, dw, (double*)ws,
+                           N, Cin, L, Cout, Lo, stride, pad);
+        if (slices > 1) {
+            const int64_t n = (int64_t)Cout * Cin * 3;
+            hipLaunchKernelGGL(conv1d_dw_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ws, slices, n, dw);
+        }
+    } else
         hipLaunchKernelGGL(conv1d_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dz, dw, N, Cin, L, Cout, Lo, stride, pad);
     GN_LAUNCH_CHECK("conv1d_bwd.dw");
     hipLaunchKernelGGL(conv1d_db_kernel, dim3(Cout), dim3(256), 0, st, dz, db, N, Cout, Lo);

@@ -416,8 +416,10 @@ def conv1d_bwd(x, dz, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
     _chk(x, dz, w, dx, dw, db)
     Lo = (L + 2 * pad - 3) // stride + 1
     assert x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo
+    nbytes = lib().goalnet_conv1d_bwd_ws_bytes(N, Cin, Cout)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device) if nbytes else None
     check(lib().goalnet_conv1d_bwd(x.data_ptr(), dz.data_ptr(), w.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), N, Cin, L, Cout,
-                                   stride, pad, _s()), "conv1d_bwd")
+                                   stride, pad, _p(ws), nbytes, _s()), "conv1d_bwd")
 
 
 def relu_bwd(dy, y, dz):

@@ -208,9 +208,11 @@ int goalnet_mul(const float* x, int64_t ldx, const float* mult, int64_t ldmult, 
 /* y[n][co][lo] = [relu](b[co] + sum_{ci,k} x[n][ci][stride*lo - pad + k] * w[co][ci][k]), k = 3 */
 int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu, float* y,
                        int N, int Cin, int L, int Cout, int stride, int pad, void* stream);
-/* dz = grad wrt pre-activation. dx nullable (first layer needs none). */
+/* dz = grad wrt pre-activation. dx nullable (first layer needs none). ws (nullable, goalnet_conv1d_bwd_ws_bytes; 0 for few
+ * frames): fp64 partial sums of the weight gradient over frame slices, added in slice order. */
+size_t goalnet_conv1d_bwd_ws_bytes(int N, int Cin, int Cout);
 int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* dx, float* dw, float* db,
-                       int N, int Cin, int L, int Cout, int stride, int pad, void* stream);
+                       int N, int Cin, int L, int Cout, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 /* dz = dy * (y > 0) */
 int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream);
 

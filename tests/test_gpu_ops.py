@@ -286,7 +286,7 @@ def test_linear_bwd_dw(m, k, j, affine):
     close("colsum", out, dy.double().sum(0), rtol=1e-6)
 
 
-@pytest.mark.parametrize("n,bins", [(1, 30), (10, 30), (33, 17), (70, 30), (257, 21)])      # >= 64 frames: the many-frame gradient kernels
+@pytest.mark.parametrize("n,bins", [(1, 30), (10, 30), (33, 17), (70, 30), (257, 21), (515, 30)])      # >= 64 frames: the many-frame gradient kernels; >= 512: frame slices
 def test_audbl_conv1d(n, bins):
     x = rnd(n, 30, bins, seed=35, lo=-50, hi=50)
     w1 = rnd(64, 30, 3, seed=36, lo=-0.1, hi=0.1); b1 = rnd(64, seed=37)
