@@ -519,9 +519,11 @@ int launch_splitk_reduce(const char* name, const float* slabs, int nsplit, int64
 
 // split count so that the grid has about 1024 blocks but every split keeps >= 8 K-tiles
 int pick_splits(int64_t tiles, int ktiles) {
-    if (ktiles < 64) return 1;
-    int64_t s = (1024 + tiles - 1) / tiles;
-    const int64_t smax = ktiles / 8 > 1 ? ktiles / 8 : 1;
+    if (ktiles < 8 || (ktiles < 64 && tiles >= 128)) return 1;
+    // short reductions with few output tiles (the fusion MLP at hundreds of frames: 8 - 40 tiles, 8 - 32 K-tiles) left most
+    // CUs idle: ~256 blocks of >= 4 K-tiles each
+    int64_t s = ((ktiles < 64 ? 256 : 1024) + tiles - 1) / tiles;
+    const int64_t smax = ktiles < 64 ? ktiles / 4 : (ktiles / 8 > 1 ? ktiles / 8 : 1);
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     const int kps = (int)((ktiles + s - 1) / s);
