@@ -442,6 +442,8 @@ class AVM(nn.Module):
         # ---- VisBl, utils.py:172-195
         y1 = torch.empty(n, h1, w1, 64, dtype=F32, device=dev)
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
+        # block 1 keeps its pooled activation in fp32 also under precision="bf16": measured with bf16 p1 the forward logit
+        # error more than doubles (MAE 4.7e-5 -> 1.1e-4) and after 7 Adam steps it crosses 1e-3 (3.7e-4 -> 1.1e-3) for 0.6 ms
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
         del y1          # the conv output is only an input of the pool: backward reads the ReLU mask off p (csrc/pool_bn.hip)
         bf = self.precision == "bf16"

@@ -686,7 +686,7 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
 int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
                                float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                                void* stream) {
-    GN_REQUIRE(dz && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_t: null pointer");
+    GN_REQUIRE(dz && p && idx && coef3 && (dy || dy_pad_bf16) && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_t: null pointer");
     GN_PARTS_OK("bnpool_bwd_bf16p_t");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: bad dims (C %% 32)");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&

@@ -158,6 +158,11 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dbias_partials)
     npool = N * (Hc - 2) * (Wc - 2) * C
     assert dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C
+    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
+        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
+                                               idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), None, dbias_partials.data_ptr(),
+                                               _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p_t")
+        return
     check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
                                    dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd")
 

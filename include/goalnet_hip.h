@@ -105,7 +105,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                              void* stream);
-/* same with dz and p each fp32 (flag 0) or bf16 (flag 1) */
+/* same with dz and p each fp32 (flag 0) or bf16 (flag 1); either output may be NULL (not both) */
 int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
                                float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
                                void* stream);
