@@ -12,25 +12,38 @@ before the timed region. N > 1 is weak scaling: every rank trains its own 64 cli
 MSE, as an independent reference process would), gradients are summed over RCCL/xGMI in three buckets
 overlapped with backward and averaged inside the fused Adam (cvml_goalnet_amd/ddp.py).
 
-Extra objects on the JSON line:
-  roofline      the dominant kernel = the fp32-MFMA implicit-GEMM convolution forward (conv2 + conv3, 84 % of
-                forward MACs): algorithmic flops of its launches / their duration, measured with HIP events
-                inside the timed steps; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+The headline (`value`, `dtype`, `roofline`) is the REFERENCE'S PRECISION: `--dtype f32` (default), every contraction on
+the fp32 matrix cores (`v_mfma_f32_32x32x2_f32`), timed over the full --steps / --warmup. The reduced-precision engine
+(bf16 MFMA contractions, fp32 accumulation / statistics / master weights / Adam; an extension — the reference has no such
+mode) is measured in the same run, with the same K / W, and reported beside it as `bf16_path`.
+
+Objects on the JSON line:
+  roofline      the dominant kernel = the implicit-GEMM convolution forward (conv2 + conv3, 84 % of forward MACs):
+                algorithmic flops of its launches / their duration, measured with HIP events inside the timed steps;
+                peak = 157.3 TFLOP/s (fp32 MFMA) / 2 500 TFLOP/s (dense bf16 MFMA), MI355X_MICROARCH.md. `kernel` is
+                the template the library's dispatcher selects for these dims (goalnet_conv3x3_fwd*_kernel_name);
+                `traffic` comes from profiles/conv_fwd_traffic_<dtype>.json (separate --pmc FETCH_SIZE / WRITE_SIZE
+                passes of this same command, scripts/profile_bench.sh) and is reported only while the kernel's source
+                files still hash to what was profiled — null otherwise.
   cpu_baseline  the oracle (CPU restatement of the reference, oracle/avm_ref.py) timed on this host's cores on a
                 bounded sample (1 clip = 16 frames of 224x224 per step), rank 0, N = 1 only.
-  parity        logit MAE / max-abs of the HIP forward vs that CPU reference on the same 16 frames and weights: on the
-                random-init weights before the first optimizer step, and again on the weights the timed steps left.
-  roofline_fp32_path  (bf16 runs, N = 1 only) the same workload with precision="fp32" — the reference's arithmetic on the
-                fp32 matrix cores — so that the line carries the fp32-MFMA roofline of the conv forward next to the bf16 one.
+  parity        pre-sigmoid logit MAE / max-abs of the HIP forward vs that CPU reference on the same 32 frames (n > 16: the
+                branch the timed step runs), weights and dropout masks: on the random-init weights before the first
+                optimizer step, and again on the weights the W + K steps left.
+  bf16_path     (N = 1, --dtype f32) ms_per_step, clips_per_s, roofline, other_kernels, parity of precision="bf16".
+  comm          (N > 1) ranks, exchange mode, bytes per bucket, a stand-alone all-reduce of bucket 1 (algorithm bandwidth)
+                and the exposed (non-overlapped) wait per step, max over ranks.
   native_40x40_loop  SURVEY.md §8(d) "report additionally frames/s at the reference-native 40x40": the reference's own
                 operating point (main.py:169-198: one video at a time, 10 frames per optimizer step, fp32), run by
-                loop.VideoTrainer as one HIP-graph launch per sub-batch; N = 1 only, a few seconds.
+                loop.VideoTrainer as one HIP-graph launch per sub-batch, with the CPU oracle's step beside it; N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -43,10 +56,61 @@ if ROOT not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (not the 2:1-sparsity marketing figure)
 FRAMES_PER_CLIP = 16
+PROBE_FRAMES = 32               # > 16: AVM.forward_device's bf16 linear5 / p3 / y3 branches, i.e. what the timed step runs
+
+# the source files each conv-forward kernel is built from: roofline.traffic is only as current as these
+KERNEL_SOURCES = {
+    "f32": ["gemm_f32.hip", "gemm_common.h", "common.h"],
+    "bf16": ["gemm_bf16_256.hip", "gemm_bf16.hip", "gemm_bf16_common.h", "gemm_common.h", "common.h"],
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_sources_sha(dtype):
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[dtype]:
+        h.update(open(os.path.join(ROOT, "cvml_goalnet_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _norm(name):
+    return re.sub(r"\s+|\(anonymous namespace\)::|goalnet::", "", name or "")
+
+
+def conv_fwd_kernel(dtype, n, h, w):
+    """The kernel template the library dispatches conv3's forward to at this size (conv2 takes the same template)."""
+    from cvml_goalnet_amd import AVM, ops
+    (_, _), _, (hp2, wp2), _ = AVM._sizes(h, w)
+    lib = ops.lib()
+    if dtype == "bf16":
+        raw = lib.goalnet_conv3x3_fwd_bf16p_kernel_name(n, hp2, wp2, 256, 512, 1).decode()
+        base = "gemm_bf16_256_kernel" if "256" in raw.split("[")[0] else "gemm_bf16_kernel"
+    else:
+        raw = lib.goalnet_conv3x3_fwd_kernel_name(n, hp2, wp2, 256, 512, 1).decode()
+        base = "gemm_f32_kernel"
+    m = re.search(r"\[(.*)\]", raw)
+    args = [a.split("=", 1)[1].strip() for a in m.group(1).split(", ") if "=" in a] if m else []
+    args = [a.replace("(anonymous namespace)::", "").replace("goalnet::", "") for a in args]
+    return f"{base}<{', '.join(args)}>"
+
+
+def traffic_of(dtype, kernel, clips, h):
+    """HBM bytes per launch of `kernel` from the committed --pmc summary, or (None, why)."""
+    tj = os.path.join(ROOT, "profiles", f"conv_fwd_traffic_{dtype}.json")
+    if not (os.path.exists(tj) and clips == 64 and h == 224):
+        return None, "no counter summary for this workload"
+    try:
+        j = json.load(open(tj))
+    except Exception as e:
+        return None, f"unreadable {tj}: {e!r}"
+    if _norm(j.get("kernel")) != _norm(kernel):
+        return None, f"counter summary is for {j.get('kernel')!r}, the dispatcher now selects {kernel!r}"
+    if j.get("sources_sha256") != kernel_sources_sha(dtype):
+        return None, "kernel sources changed since the counter passes (re-run scripts/profile_bench.sh pmc)"
+    return j.get("hbm_bytes_per_launch"), f"{j.get('source')} @ {j.get('git_head')}"
 
 
 def make_inputs(n, h, w, device, seed):
@@ -63,12 +127,14 @@ def make_inputs(n, h, w, device, seed):
 
 
 def logit_parity(model, h, w, seed):
-    """Logits of the HIP forward vs the CPU oracle on the same 16 frames, weights and dropout masks (regenerated from the
-    seed formula on both sides); BatchNorm in train mode. The probe restores the model's BatchNorm buffers."""
+    """Logits of the HIP forward vs the CPU oracle on the same PROBE_FRAMES frames, weights and dropout masks (regenerated
+    from the seed formula on both sides); BatchNorm in train mode. The probe restores the model's BatchNorm buffers."""
     from cvml_goalnet_amd import synth
     from oracle import avm_ref
-    n = FRAMES_PER_CLIP
+    n = PROBE_FRAMES
     aud, vis, lab = make_inputs(n, h, w, model._device, seed + 1)
+    if not model.audio_included:
+        aud = None
     if not model._materialized:
         with torch.no_grad():
             model.forward_device(aud, vis, save=False)               # Lazy parameters take their random init here
@@ -88,7 +154,8 @@ def logit_parity(model, h, w, seed):
         getattr(*model._module_of(k)).copy_(v)
     inter = {}
     with torch.no_grad():
-        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, aud.cpu(), vis.cpu(), masks, model.audio_included, inter)
+        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, None if aud is None else aud.cpu(), vis.cpu(), masks,
+                        model.audio_included, inter)
     ref_logit = inter["logit"].view(-1)
     d = (hip_logit - ref_logit).abs()
     return {"logit_mae_vs_cpu_ref": d.mean().item(), "logit_maxabs_vs_cpu_ref": d.max().item(),
@@ -113,7 +180,7 @@ def cpu_baseline(model, h, w, seed, max_seconds=40.0):
     t_begin = time.time()
     for i in range(3):
         t0 = time.time()
-        avm_ref.train_step(p, b, state, a_c, v_c, l_c, masks, model.audio_included)
+        avm_ref.train_step(p, b, state, a_c if model.audio_included else None, v_c, l_c, masks, model.audio_included)
         times.append(time.time() - t0)
         if time.time() - t_begin > max_seconds:
             break
@@ -123,32 +190,80 @@ def cpu_baseline(model, h, w, seed, max_seconds=40.0):
                       f"{len(times)} steps, best of the non-first: {t:.2f} s/step"}
 
 
-def fp32_path_roofline(dev, n, h, w, audio, seed):
-    """The same step on the reference's own arithmetic (precision="fp32": fp32 MFMA, `v_mfma_f32_32x32x2_f32`): two timed
-    steps, conv2 + conv3 forward launches bracketed with HIP events exactly as for the main roofline object."""
-    from cvml_goalnet_amd import AVM
-    model = AVM(audio_included=audio, device=dev, seed=seed, precision="fp32")
-    aud, vis, lab = make_inputs(n, h, w, dev, seed)
-    if not audio:
-        aud = None
-    for _ in range(2):
-        model.train_step(aud, vis, lab)
-    model.kernel_events = {}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        model.train_step(aud, vis, lab)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 2
-    ev = model.kernel_events["conv_fwd"]
-    model.kernel_events = None
+def roofline_of(events, dtype, n, h, w, clips):
+    ev = events.get("conv_fwd", [])
+    if not ev:
+        return None, {}
     ms = [a.elapsed_time(b) for a, b, _ in ev]
     fl = [f for _, _, f in ev]
     achieved = sum(fl) / (sum(ms) * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-            "kernel": "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)",
-            "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms), "ms_per_step": 1e3 * dt,
-            "clips_per_s": (n / FRAMES_PER_CLIP) / dt, "dtype": "f32"}
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+    kname = conv_fwd_kernel(dtype, n, h, w)
+    traffic, src = traffic_of(dtype, kname, clips, h)
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "traffic_source": src, "kernel": kname + " (conv2 + conv3 forward, implicit GEMM; name from the library's dispatcher)",
+            "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms), "algorithmic_flops_per_launch": sum(fl) / len(fl)}
+    others = {}
+    for k, lst in events.items():
+        if k == "conv_fwd":
+            continue
+        t = sum(a.elapsed_time(b) for a, b, _ in lst) * 1e-3
+        others[k] = {"tflops": sum(f for _, _, f in lst) / t / 1e12, "ms_per_launch": 1e3 * t / len(lst), "launches": len(lst)}
+    return roof, others
+
+
+def timed_steps(model, aud, vis, lab, warmup, steps, distributed, dev):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        model.train_step(aud, vis, lab)
+    model.kernel_events = {}
+    if model.grad_sync is not None:
+        model.grad_sync.timing = {}
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, pred = model.train_step(aud, vis, lab)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    events = model.kernel_events
+    model.kernel_events = None
+    assert torch.isfinite(loss).all() and torch.isfinite(pred).all(), "non-finite loss/prediction"
+    return dt, events, loss
+
+
+def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clips, with_parity):
+    """The same workload, K and W on the other engine (N = 1 only): its own ms/step, roofline and parity."""
+    from cvml_goalnet_amd import AVM, synth
+    torch.manual_seed(1234)
+    model = AVM(audio_included=audio, device=dev, seed=seed, precision="bf16" if dtype == "bf16" else "fp32")
+    aud, vis, lab = make_inputs(n, h, w, dev, seed)
+    if not audio:
+        aud = None
+    parity = None
+    if with_parity:
+        parity = logit_parity(model, h, w, synth.BASE_SEED)
+        parity.update({"weights": "random init (before the first optimizer step)", "dropout": "masks from seed formula", "bn": "train"})
+        torch.cuda.empty_cache()
+    dt, events, loss = timed_steps(model, aud, vis, lab, warmup, steps, False, dev)
+    roof, others = roofline_of(events, dtype, n, h, w, clips)
+    out = {"dtype": dtype, "ms_per_step": 1e3 * dt / steps, "clips_per_s": clips * steps / dt, "steps": steps, "warmup": warmup,
+           "final_loss": float(loss.item()), "roofline": roof, "other_kernels": others,
+           "arithmetic": "bf16 MFMA contractions (conv2/conv3 fwd+dgrad+wgrad, linear5), bf16 storage of the activations between them; "
+                         "fp32 accumulation, BatchNorm statistics, block 1, AudBl, fusion MLP, loss, gradients, master weights, Adam"
+                         if dtype == "bf16" else "fp32 MFMA everywhere (the reference's arithmetic)"}
+    if parity is not None:
+        parity[f"after_{warmup + steps}_adam_steps"] = logit_parity(model, h, w, synth.BASE_SEED)
+        out["parity"] = parity
+    return out
 
 
 def native40_loop(dev, frames=300, videos=3):
@@ -169,35 +284,60 @@ def native40_loop(dev, frames=300, videos=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = videos * ((frames + 9) // 10)
-    # the same 10-frame train step by the CPU oracle on this host's cores (what the reference's own loop costs per step)
-    cpu_us, cpu_threads = None, None
+    # the same train step by the CPU oracle on this host's cores (what the reference's own loop costs per step), and the
+    # SURVEY.md §8(d) CPU points at 40x40: N = 10 (the reference's sub-batch), 64, 1024
+    cpu = {}
     try:
         from oracle import avm_ref
         sd = model.state_dict()
         p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
         b = {k: v.clone() for k, v in sd.items() if k not in p}
-        a_c, v_c, l_c = aud[:10].cpu(), vis[:10].cpu(), lab[:10].cpu()
-        masks = [torch.from_numpy(m) for m in synth.make_drop_masks(10, step=0)]
-        best = None
         all_threads = torch.get_num_threads()
-        for th in sorted({8, all_threads}):              # small tensors: more threads are not faster; report the better setting
-            torch.set_num_threads(th)
-            state, ts = {}, []
-            pp = {k: v.clone() for k, v in p.items()}
-            bb = {k: v.clone() for k, v in b.items()}
-            for _ in range(5):
-                t1 = time.perf_counter()
-                avm_ref.train_step(pp, bb, state, a_c, v_c, l_c, masks, True)
-                ts.append(time.perf_counter() - t1)
-            if best is None or min(ts[1:]) < best[0]:
-                best = (min(ts[1:]), th)
-        torch.set_num_threads(all_threads)
-        cpu_us, cpu_threads = 1e6 * best[0], best[1]
+        for nn, reps in ((10, 5), (64, 4), (1024, 2)):
+            reps_n = (nn + frames - 1) // frames
+            a_c = aud.cpu().repeat(reps_n, 1, 1)[:nn]; v_c = vis.cpu().repeat(reps_n, 1, 1, 1)[:nn]; l_c = lab.cpu().repeat(reps_n)[:nn]
+            masks = [torch.from_numpy(m) for m in synth.make_drop_masks(nn, step=0)]
+            best = None
+            for th in sorted({8, all_threads}):          # small tensors: more threads are not always faster; report the better setting
+                torch.set_num_threads(th)
+                state, ts = {}, []
+                pp = {k: v.clone() for k, v in p.items()}
+                bb = {k: v.clone() for k, v in b.items()}
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    avm_ref.train_step(pp, bb, state, a_c, v_c, l_c, masks, True)
+                    ts.append(time.perf_counter() - t1)
+                if best is None or min(ts[1:]) < best[0]:
+                    best = (min(ts[1:]), th)
+            torch.set_num_threads(all_threads)
+            cpu[f"n{nn}"] = {"us_per_step": 1e6 * best[0], "frames_per_s": nn / best[0], "threads": best[1]}
     except Exception as e:
         log(f"cpu oracle at 40x40 failed: {e!r}")
-    return {"frames_per_s": videos * frames / dt, "cpu_oracle_us_per_step": cpu_us, "cpu_threads": cpu_threads, "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
+    return {"frames_per_s": videos * frames / dt, "cpu_oracle_us_per_step": cpu.get("n10", {}).get("us_per_step"),
+            "cpu_threads": cpu.get("n10", {}).get("threads"), "cpu_oracle_train_step_40x40": cpu,
+            "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
             "dtype": "f32", "mode": "one HIP graph launch per sub-batch (loop.VideoTrainer)", "graph_replays": tr.replays,
             "eager_steps": tr.eager_steps, "videos": videos, "frames_per_video": frames, "last_batch_loss": batch_loss}
+
+
+def comm_probe(model, dev, world):
+    """stand-alone all-reduce of bucket 1's size on the idle machine: what the exchange costs when nothing hides it"""
+    import torch.distributed as dist
+    from cvml_goalnet_amd.ddp import bucket_slices
+    sl = bucket_slices(model._specs, model._arena_numel)
+    t = torch.zeros(sl[1][1] - sl[1][0], dtype=torch.float32, device=dev)
+    for _ in range(2):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    nbytes = t.numel() * 4
+    return {"bytes": nbytes, "ms": ms, "algorithm_GBps": nbytes / ms / 1e6,
+            "bus_GBps": nbytes / ms / 1e6 * 2 * (world - 1) / max(world, 1)}, [4 * (b - a) for a, b in sl]
 
 
 def main():
@@ -210,12 +350,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true")
     ap.add_argument("--no-native40", action="store_true", help="skip the extra 40x40 / 10-frame loop measurement")
+    ap.add_argument("--no-second-path", action="store_true", help="skip the other precision's measurement (bf16_path / fp32_path)")
     ap.add_argument("--global-batch", action="store_true",
                     help="N > 1: BatchNorm statistics and the broadcast MSE over all ranks' frames, gradients summed "
                          "(ddp.SyncStats: the step equals one reference process on the global batch)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "bf16"),
-                    help="bf16 (default) = bf16-MFMA contractions with fp32 accumulation/statistics/master weights, logits within "
-                         "the north star's 1e-3 of the fp32 CPU reference; f32 = the reference's arithmetic on the fp32 matrix cores")
+    ap.add_argument("--no-shard", action="store_true",
+                    help="N > 1: all-reduce linear5.weight's gradient and run the replicated Adam instead of reduce-scatter + "
+                         "Adam on the rank's slice + all-gather of the updated weights")
+    ap.add_argument("--compress-bf16", action="store_true",
+                    help="N > 1, --no-shard: exchange linear5.weight's gradient as bf16 (an extension; off = exact fp32 sums)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "f32"),
+                    help="f32 (default) = the reference's arithmetic on the fp32 matrix cores; bf16 = bf16-MFMA contractions with "
+                         "fp32 accumulation / statistics / master weights (an extension)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): anything libraries print meanwhile (RCCL prints a version banner to
@@ -247,54 +393,48 @@ def main():
     n = args.clips * FRAMES_PER_CLIP
     h = w = args.hw
     seed = synth.BASE_SEED + rank
-    torch.manual_seed(1234)                                   # same initial weights on every rank
+    torch.manual_seed(1234 + rank)          # ranks build DIFFERENT models on purpose: GradSync.sync_params makes them one
     model = AVM(audio_included=not args.no_audio, device=dev, seed=seed, precision="bf16" if args.dtype == "bf16" else "fp32")
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if args.no_audio:
         aud = None
-    if distributed and args.global_batch:
-        from cvml_goalnet_amd.ddp import enable_global_batch
-        enable_global_batch(model, compress="bf16" if args.dtype == "bf16" else None)
-    elif distributed:
-        model.grad_sync = GradSync(compress="bf16" if args.dtype == "bf16" else None)
+    comm = None
+    if distributed:
+        compress = "bf16" if args.compress_bf16 else None
+        if args.global_batch:
+            from cvml_goalnet_amd.ddp import enable_global_batch
+            enable_global_batch(model, compress=compress, shard_linear5=not args.no_shard)
+        else:
+            model.grad_sync = GradSync(compress=compress, shard_linear5=not args.no_shard)
 
+    single = rank == 0 and world == 1
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         try:
             parity = logit_parity(model, h, w, synth.BASE_SEED)     # on the random-init weights, before any optimizer step
             parity.update({"weights": "random init (before the first optimizer step)", "dropout": "masks from seed formula", "bn": "train"})
         except Exception as e:
             log(f"parity probe failed: {e!r}")
-        torch.cuda.empty_cache()            # the probe's 16-frame buffers must not fragment the pool the 1024-frame steps use
+        torch.cuda.empty_cache()            # the probe's buffers must not fragment the pool the 1024-frame steps use
     if distributed:
         # RCCL builds its communicator, channels and staging buffers lazily on the first collectives of each kind (seen with one
         # forced rank: +80 ms per step over the first steps): get that out of the way before the W warm-up steps
-        for dt_ in (torch.float32, torch.bfloat16):
-            t = torch.zeros(64 << 20, dtype=dt_, device=dev)
-            for _ in range(2):
-                dist.all_reduce(t)
-        torch.cuda.synchronize()
-        del t
-    for _ in range(args.warmup):
-        model.train_step(aud, vis, lab)
-    model.kernel_events = {}
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, pred = model.train_step(aud, vis, lab)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    events = model.kernel_events
-    model.kernel_events = None
-    assert torch.isfinite(loss).all() and torch.isfinite(pred).all(), "non-finite loss/prediction"
+        with torch.no_grad():
+            model.forward_device(aud[:2] if aud is not None else None, vis[:2], save=False)      # materialise + sync_params
+        probe, bucket_bytes = comm_probe(model, dev, world)
+        sharded = model.grad_sync.sharded(model)
+        comm = {"ranks": world, "backend": "nccl (RCCL over xGMI)", "bucket_bytes": bucket_bytes,
+                "mode": ("bucket 1 (linear5.weight): reduce-scatter -> Adam on the rank's 1/%d slice -> asynchronous all-gather of the "
+                         "updated weights (waited for before the next step's linear5); buckets 0, 2: all-reduce" % world) if sharded
+                        else "all-reduce of three buckets overlapped with backward, replicated fused Adam",
+                "allreduce_probe_bucket1": probe, "compress": compress}
+    dt, events, loss = timed_steps(model, aud, vis, lab, args.warmup, args.steps, distributed, dev)
+    if comm is not None and model.grad_sync.timing:
+        ev = model.grad_sync.timing.get("exposed_ms", [])
+        ex = torch.tensor([sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        comm["exposed_wait_ms_per_step_max_over_ranks"] = ex.item()
+        model.grad_sync.timing = None
 
     if rank == 0:
         clips = args.clips * world * args.steps
@@ -309,37 +449,16 @@ def main():
                        "parallelism": f"dp{world}", "ddp_semantics": ("BatchNorm sums + broadcast MSE over all ranks' frames, gradient sum (global batch)"
                                                                  if distributed and args.global_batch else
                                                                  "local BN + local MSE per rank, gradient mean (standard DDP)") +
-                       ("; linear5.weight gradient exchanged as bf16" if args.dtype == "bf16" and distributed else ""),
+                       ("; linear5.weight gradient exchanged as bf16" if args.compress_bf16 and distributed else ""),
                        "params": int(sum(s.numel for s in model._specs)), "final_loss": float(loss.item())},
         }
-        ev = events.get("conv_fwd", [])
-        if ev:
-            ms = [a.elapsed_time(b) for a, b, _ in ev]
-            fl = [f for _, _, f in ev]
-            achieved = sum(fl) / (sum(ms) * 1e-3) / 1e12
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", f"conv_fwd_traffic_{args.dtype}.json")
-            if os.path.exists(tj) and args.clips == 64 and h == 224:
-                try:
-                    traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
-            kname = ("gemm_bf16_256_kernel<ConvAPadLoader256<64>, KCLoader256<32>, 0> (conv2 + conv3 forward, bf16 MFMA implicit GEMM, 256x256 phased tile, zero-padded bf16 activations)" if args.dtype == "bf16"
-                     else "gemm_f32_kernel<ConvALoader<true>, KCLoader<false>> (conv2 + conv3 forward, fp32 MFMA implicit GEMM)")
-            res["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                               "frac": achieved / peak, "traffic": traffic,
-                               "kernel": kname,
-                               "launches": len(ms), "avg_launch_ms": sum(ms) / len(ms),
-                               "algorithmic_flops_per_launch": sum(fl) / len(fl)}
-            others = {}
-            for k, lst in events.items():
-                if k == "conv_fwd":
-                    continue
-                t = sum(a.elapsed_time(b) for a, b, _ in lst) * 1e-3
-                others[k] = {"tflops": sum(f for _, _, f in lst) / t / 1e12, "ms_per_step": 1e3 * t / args.steps}
+        roof, others = roofline_of(events, args.dtype, n, h, w, args.clips)
+        if roof is not None:
+            res["roofline"] = roof
             res["other_kernels"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if comm is not None:
+            res["comm"] = comm
+        if single and not args.no_cpu_baseline:
             try:
                 if parity is not None:
                     after = logit_parity(model, h, w, synth.BASE_SEED)
@@ -349,18 +468,24 @@ def main():
             except Exception as e:  # the bench line must still be printed
                 log(f"cpu_baseline failed: {e!r}")
                 res["cpu_baseline"] = None
-        if world == 1 and not args.no_native40:
-            try:
-                del model, aud, vis, lab
+        if single:
+            del model, aud, vis, lab
+            torch.cuda.empty_cache()
+            if not args.no_second_path:
+                other = "bf16" if args.dtype == "f32" else "f32"
+                try:
+                    res[("bf16" if other == "bf16" else "fp32") + "_path"] = reduced_precision_path(
+                        dev, other, n, h, w, not args.no_audio, seed, args.steps, args.warmup, args.clips, not args.no_cpu_baseline)
+                except Exception as e:
+                    log(f"{other} path failed: {e!r}")
+                    res[("bf16" if other == "bf16" else "fp32") + "_path"] = None
                 torch.cuda.empty_cache()
-                if args.dtype == "bf16":
-                    # the reference is fp32: the same workload on the fp32 matrix cores, for the fp32-MFMA roofline
-                    res["roofline_fp32_path"] = fp32_path_roofline(dev, n, h, w, not args.no_audio, seed)
-                    torch.cuda.empty_cache()
-                res["native_40x40_loop"] = native40_loop(dev)
-            except Exception as e:
-                log(f"native 40x40 loop failed: {e!r}")
-                res["native_40x40_loop"] = None
+            if not args.no_native40:
+                try:
+                    res["native_40x40_loop"] = native40_loop(dev)
+                except Exception as e:
+                    log(f"native 40x40 loop failed: {e!r}")
+                    res["native_40x40_loop"] = None
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "goalnet_conv3x3_fwd_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_fwd_bf16p_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_cast_bf16": (c_int, [P, P, c_int64, P]),
@@ -87,7 +89,7 @@ PROTOTYPES = {
     "goalnet_mse_bcast": (c_int, [P, P, c_int, P, P, P]),
     "goalnet_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, P]),
     "goalnet_counter_add": (c_int, [P, c_int64, P]),
-    "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, P]),
+    "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, c_int64, P]),
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
     "goalnet_adam_step_dev_shadow": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,
                                              c_int64, P]),

@@ -71,7 +71,11 @@ class _Spec:
 
 
 class AVM(nn.Module):
-    def __init__(self, audio_included, device=None, seed: int = BASE_SEED, precision: str = "fp32"):
+    def __init__(self, audio_included, device=None, seed: Optional[int] = None, precision: str = "fp32"):
+        """`seed`: seed of the counter-based dropout stream. None (default) draws it from the torch RNG at construction, so
+        dropout follows `torch.manual_seed` as the reference's does (utils.py:170, 245-254 use the global torch RNG) and two
+        model instances / two runs do not replay the same masks; parity tests pass synth.BASE_SEED to regenerate the masks
+        from the seed formula on the CPU side."""
         super().__init__()
         self.audio_included = audio_included                      # utils.py:235
         if precision not in ("fp32", "bf16"):
@@ -101,7 +105,8 @@ class AVM(nn.Module):
         # dropout (utils.py:170, 245-254): "device" = counter-based masks (synth.make_drop_masks formula),
         # "off" = p := 0, "given" = masks supplied through set_dropout_masks() (parity tests)
         self.dropout_mode = "device"
-        self.dropout_seed = seed
+        self.dropout_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seed is None else int(seed)
+        self.dropout_row_offset = 0    # rows in front of this rank's rows in the global batch (ddp.enable_global_batch)
         self._drop_step = 0
         self._given_masks: Optional[List[torch.Tensor]] = None
 
@@ -109,6 +114,7 @@ class AVM(nn.Module):
         self._arena = self._garena = self._adam_m = self._adam_v = None
         self._hw3 = self._l2 = None
         self._adam_t = 0
+        self._adam_segs = None
         self._w5b, self._w5b_version = None, None      # bf16 shadow of visbl.linear5.weight and the version stamps it matches
         self._load_count = 0                           # bumped by load_state_dict (its layout kernels write the arena directly)
         self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
@@ -121,6 +127,7 @@ class AVM(nn.Module):
         self.act_bf16 = os.environ.get("GOALNET_P16", "1") != "0"     # precision="bf16": pooled activations of blocks 2, 3 stored as bf16
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
+        self.last_used_w5b = False
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
     # ------------------------------------------------------------------------------------------
@@ -242,6 +249,8 @@ class AVM(nn.Module):
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         if not self._materialized:
             raise RuntimeError("state_dict() before the first forward / load_state_dict(): parameters are uninitialised")
+        if self.grad_sync is not None:
+            self.grad_sync.gather_master(self)           # ddp.GradSync(shard_linear5=True): a collective when slices are stale
         out = {} if destination is None else destination
         order = self._reference_key_order()
         for name in order:
@@ -331,7 +340,10 @@ class AVM(nn.Module):
         # one launch for the five masks; the draw index is the device counter state[1] (graph-capturable)
         widths = (512, 512, 512, 256, 128)
         buf = torch.empty(n * sum(widths), dtype=F32, device=self._device)
-        out = ops.dropout_masks_dev(buf, n, widths, self.dropout_seed, TID_DROP, 8, self._state[1], DROP_P)
+        # global-batch mode: this rank draws rows [rank * n, (rank + 1) * n) of the masks one process would draw for the
+        # concatenated batch; standard DDP: an independent stream per rank (ddp.GradSync.sync_params re-seeds)
+        row0 = self.stat_sync.rank * n if self.stat_sync is not None else self.dropout_row_offset
+        out = ops.dropout_masks_dev(buf, n, widths, self.dropout_seed, TID_DROP, 8, self._state[1], DROP_P, row_offset=row0)
         if self._defer_tick:
             self._pending_drop_tick = 1          # train_step advances all counters in one launch at its end
         else:
@@ -347,6 +359,8 @@ class AVM(nn.Module):
         (ops.adam_step_dev_shadow), so the next forward needs no 7.7 GB cast pass; any other writer (a stock torch optimizer,
         load_state_dict, in-place edits of the Parameter or of the arena) changes `_w5_version()` and the copy is re-made."""
         w5 = self._pflat("visbl.linear5.weight")
+        if self.grad_sync is not None and self.grad_sync.master_stale and self._w5b_version != self._w5_version():
+            self.grad_sync.gather_master(self)           # the copy is invalid AND foreign slices of the master are stale
         if self._w5b is None or self._w5b.numel() != w5.numel():
             self._w5b, self._w5b_version = torch.empty(w5.numel(), dtype=torch.bfloat16, device=self._device), None
         if self._w5b_version != self._w5_version():
@@ -393,9 +407,16 @@ class AVM(nn.Module):
         return self.stat_sync.all_reduce(row)
 
     @staticmethod
+    def _bwd16_ok(wc):
+        """widths goalnet_bnpool_bwd_bf16p(_t) serves: three pooled rows of a 32-channel slice (value + argmax byte) in 64 KB
+        of LDS, i.e. conv outputs up to 138 pixels wide (frames up to ~416 px); wider blocks take the fp32 kernels"""
+        return 3 * (wc - 2) * 32 * 5 <= 65536
+
+    @staticmethod
     def _p16_ok(wc, c):
-        """shapes goalnet_pool_bnstats_fwd_p16 serves (32-channel slices, three conv rows in 64 KB of LDS)"""
-        return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536
+        """shapes goalnet_pool_bnstats_fwd_p16 serves (32-channel slices, three conv rows in 64 KB of LDS) and whose bf16
+        pooled activation the fused backward can read back"""
+        return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536 and AVM._bwd16_ok(wc)
 
     def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
         """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift).
@@ -434,6 +455,8 @@ class AVM(nn.Module):
             l1 = (bins - 1) // 2 + 1
             l2 = (l1 - 1) // 2 + 1
         self._materialize(hp3 * wp3, l2)
+        if self.grad_sync is not None:
+            self.grad_sync.ensure_params_synced(self)      # first synchronised step: every rank starts from rank 0's model
         dev = self._device
         P = self._pflat
         masks = self._masks(n)
@@ -486,6 +509,10 @@ class AVM(nn.Module):
         cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
         mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         k5 = 512 * hp3 * wp3
+        if self.grad_sync is not None:
+            # shard_linear5: the all-gather of the updated weights has been running under the convolutions above
+            self.grad_sync.wait_weights() if bf5 else self.grad_sync.gather_master(self)
+        self.last_used_w5b = bool(bf5)                  # loop.VideoTrainer: does a graph captured from this call read the bf16 copy?
         if bf5:
             xh3 = ops.bn_apply_bf16(p3, st3[2], st3[3], torch.empty(p3.shape, dtype=BF16, device=dev), 512)
             w5b = self._w5_bf16(k5)
@@ -548,10 +575,16 @@ class AVM(nn.Module):
             ops.bn_bwd_finalize(self._global_sums(partials, 2 * c), self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1],
                                 npix * self.stat_sync.world, c, scratch[:c], scratch[c:], coef3)
         dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)        # dbias partials per (frame, row band)
-        if self.precision == "bf16" and i > 1:
+        if self.precision == "bf16" and i > 1 and self._bwd16_ok(wc):
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
             dy = self._padbuf(f"dy{i}", n, hc, wc, c)
             ops.bnpool_bwd_bf16p(dbn, p, idx, coef3, None, dy, dparts, n, hc, wc, c)
+        elif self.precision == "bf16" and i > 1:
+            # frames wider than ~416 px: the rolling LDS rows of the fused bf16 kernel do not fit; fp32 kernel (dz and p are
+            # fp32 for such widths, see _p16_ok / backward_device) + one cast pass into the padded layout
+            dy32 = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
+            ops.bnpool_bwd(dbn, p, idx, coef3, dy32, dparts, n, hc, wc, c)
+            dy = ops.to_bf16_padded(dy32, None, None, self._padbuf(f"dy{i}", n, hc, wc, c), n, hc, wc, c)
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
             ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
@@ -605,7 +638,7 @@ class AVM(nn.Module):
         # stored as bf16 (fp32 accumulators rounded once, at the store): its only readers are the two HBM-bound passes of
         # _block_bwd, and the GEMMs behind them consume bf16 anyway
         dz16 = bf and self.grad_bf16
-        o16_3 = dz16 and ctx["bf5"] and ops.linear_bwd_dx_bf16_o16_ok(n, k5, 512)
+        o16_3 = dz16 and ctx["bf5"] and self._bwd16_ok(wp2) and ops.linear_bwd_dx_bf16_o16_ok(n, k5, 512)
         dbn3 = torch.empty(n, hp3, wp3, 512, dtype=torch.bfloat16 if o16_3 else F32, device=dev)
         if bf and ctx["padgen"] != (self._padgen["x1"], self._padgen["x2"]):
             raise RuntimeError("precision='bf16': a second training-mode forward overwrote the saved bf16 operands before "
@@ -638,7 +671,7 @@ class AVM(nn.Module):
                         ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
-        o16_2 = dz16 and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
+        o16_2 = dz16 and self._bwd16_ok(wp1) and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
         dbn2 = torch.empty(n, hp2, wp2, 256, dtype=torch.bfloat16 if o16_2 else F32, device=dev)
         if self.precision == "bf16":
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
@@ -748,21 +781,46 @@ class AVM(nn.Module):
         ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
+    def _adam_segments(self):
+        """[(lo, hi)] arena ranges this rank's optimizer owns: everything, or — ddp.GradSync(shard_linear5=True) — everything
+        but the foreign slices of visbl.linear5.weight"""
+        sync = self.grad_sync
+        if sync is None or not sync.sharded(self):
+            return [(0, self._arena_numel)]
+        s5 = self.spec("visbl.linear5.weight")
+        after = min(s.offset for s in self._specs if s.offset > s5.offset)
+        slo, shi = sync.shard_range(self)
+        return [(0, s5.offset), (slo, shi), (after, self._arena_numel)]
+
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True):
         """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
-        counter state[0] (= completed steps) + 1, so the same captured launch serves every step."""
-        if self._adam_m is None:
-            self._adam_m = torch.zeros_like(self._arena)
-            self._adam_v = torch.zeros_like(self._arena)
+        counter state[0] (= completed steps) + 1, so the same captured launch serves every step. With a sharded
+        linear5.weight (ddp.py) the pass covers this rank's slice only — three launches — and the optimizer state exists
+        only for what the rank owns."""
+        segs = self._adam_segments()
+        if self._adam_m is None or self._adam_segs != segs:
+            total = sum(hi - lo for lo, hi in segs)
+            self._adam_m = torch.zeros(total, dtype=F32, device=self._device)
+            self._adam_v = torch.zeros(total, dtype=F32, device=self._device)
+            self._adam_segs = segs
         self._adam_t += 1
-        if self._w5b is not None and self._w5b_version == self._w5_version():
-            # bf16 mode at > 16 rows: refresh the shadow of linear5.weight in the same pass (the kernels do not bump versions)
-            s5 = self.spec("visbl.linear5.weight")
-            ops.adam_step_dev_shadow(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
-                                     self._w5b, s5.offset, grad_scale, step_bias=1)
-        else:
-            ops.adam_step_dev(self._arena, self._garena, self._adam_m, self._adam_v, lr, betas[0], betas[1], eps, self._state[0],
-                              grad_scale, step_bias=1)
+        s5 = self.spec("visbl.linear5.weight")
+        shadow_ok = self._w5b is not None and self._w5b_version == self._w5_version()
+        off = 0
+        for lo, hi in segs:
+            cnt = hi - lo
+            p, g = self._arena[lo:hi], self._garena[lo:hi]
+            m, v = self._adam_m[off:off + cnt], self._adam_v[off:off + cnt]
+            off += cnt
+            a, b = max(lo, s5.offset), min(hi, s5.offset + s5.numel)       # the part of linear5.weight inside this segment
+            if shadow_ok and a < b:
+                # bf16 mode at > 16 rows: refresh the shadow of linear5.weight in the same pass (the kernels do not bump versions)
+                ops.adam_step_dev_shadow(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0],
+                                         self._w5b[a - s5.offset:b - s5.offset], a - lo, grad_scale, step_bias=1)
+            else:
+                ops.adam_step_dev(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0], grad_scale, step_bias=1)
+        if len(segs) > 1:
+            self.grad_sync.after_adam(self, self._w5b if shadow_ok else None)
         if _tick:
             ops.counter_add(self._state[0], 1)
 

@@ -707,6 +707,18 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
     return launch_splitk_reduce("conv3x3_fwd_bf16p.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }
 
+}  // extern "C"
+template <class AL, class BL> static const char* gemm_bf16_kernel_name() { return __PRETTY_FUNCTION__; }
+extern "C" {
+
+/* which kernel goalnet_conv3x3_fwd_bf16p(_o16) launches for these dims with a bias / ReLU epilogue (forward == 1) or a raw
+ * one (the data gradient): the dispatch above, not executed */
+const char* goalnet_conv3x3_fwd_bf16p_kernel_name(int N, int H, int W, int Cin, int Cout, int forward) {
+    (void)Cin;
+    if (conv_use_256((int64_t)N * H * W, Cout)) return conv_bf16_256_kernel_name(forward ? 0 : 1);
+    return gemm_bf16_kernel_name<ConvAPadLoaderH, KCLoaderH>();
+}
+
 /* 1 when goalnet_conv3x3_fwd_bf16p_o16 serves these dims (the shapes the 256 x 256 tile takes), else 0 */
 int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % BKH != 0 || Cout % 8 != 0) return 0;

@@ -500,6 +500,12 @@ static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_p
     return 0;
 }
 
+template <class AL, class BL, int ROLE> static const char* gemm_bf16_256_kernel_name() { return __PRETTY_FUNCTION__; }
+const char* conv_bf16_256_kernel_name(int role) {
+    return role == 0 ? gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 0>()
+                     : gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 1>();
+}
+
 // conv 3x3 forward (bias + ReLU epilogue) / data gradient (raw epilogue) on zero-padded bf16 activations, 256^2 phased tile
 int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
                          int Cout, const EpiP& ep, hipStream_t st) {

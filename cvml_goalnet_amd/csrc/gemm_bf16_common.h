@@ -42,6 +42,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* lds_dst, u
 int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
                          int Cout, const EpiP& ep, hipStream_t st);
 
+const char* conv_bf16_256_kernel_name(int role);
 int wgrad_splits_256(int64_t Mp, int Cin, int Cout);
 int linear_fwd_splits_256(int M, int64_t K, int J);
 int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_t ldx, const __hip_bfloat16* w, int M, int64_t K,

@@ -33,14 +33,15 @@ struct Widths { int w[8]; int64_t off[9]; };
 
 __global__ __launch_bounds__(256) void dropout_masks_dev_kernel(float* dst, int n, Widths ws, int layers, uint64_t seed,
                                                                  uint32_t tid_base, uint32_t tid_stride,
-                                                                 const int64_t* __restrict__ step, float p, float scale) {
+                                                                 const int64_t* __restrict__ step, float p, float scale,
+                                                                 int64_t row_offset) {
     const uint32_t s = (uint32_t)*step;
     const int64_t total = ws.off[layers];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int l = 0;
         while (l + 1 < layers && i >= ws.off[l + 1]) ++l;
         const uint64_t key = stream_key(seed, tid_base + tid_stride * s + (uint32_t)l);
-        dst[i] = unit24(key, i - ws.off[l]) >= p ? scale : 0.f;
+        dst[i] = unit24(key, i - ws.off[l] + row_offset * ws.w[l]) >= p ? scale : 0.f;
     }
 }
 
@@ -99,9 +100,9 @@ int goalnet_rows_copy_batch(const goalnet_rowcopy* segs, int count, void* stream
 }
 
 int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, uint64_t seed, uint32_t tid_base,
-                              uint32_t tid_stride, const int64_t* step, float p, void* stream) {
+                              uint32_t tid_stride, const int64_t* step, float p, int64_t row_offset, void* stream) {
     GN_REQUIRE(dst && widths && step, GOALNET_E_NULL, "dropout_masks_dev: null pointer");
-    GN_REQUIRE(n > 0 && layers >= 1 && layers <= 8 && p >= 0.f && p < 1.f, GOALNET_E_SHAPE, "dropout_masks_dev: bad dims or p");
+    GN_REQUIRE(n > 0 && layers >= 1 && layers <= 8 && p >= 0.f && p < 1.f && row_offset >= 0, GOALNET_E_SHAPE, "dropout_masks_dev: bad dims or p");
     Widths ws;
     ws.off[0] = 0;
     for (int l = 0; l < layers; ++l) {
@@ -110,7 +111,7 @@ int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, 
         ws.off[l + 1] = ws.off[l] + (int64_t)n * widths[l];
     }
     hipLaunchKernelGGL(dropout_masks_dev_kernel, dim3(grid1(ws.off[layers], 8192)), dim3(256), 0, (hipStream_t)stream, dst, n, ws,
-                       layers, seed, tid_base, tid_stride, step, p, 1.0f / (1.0f - p));
+                       layers, seed, tid_base, tid_stride, step, p, 1.0f / (1.0f - p), row_offset);
     GN_LAUNCH_CHECK("dropout_masks_dev");
     return 0;
 }

@@ -43,6 +43,7 @@ class VideoTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.graphs = graphs
         self._graphs: Dict[int, torch.cuda.CUDAGraph] = {}
+        self._uses_w5b: Dict[int, bool] = {}        # graph of size n reads the bf16 copy of linear5.weight (precision="bf16", n > 16)
         self._seen = set()
         self._pool = None
         self._cap = 0                               # frames the staging tables hold
@@ -59,6 +60,7 @@ class VideoTrainer:
         dev = m._device
         cap = max(n_frames, 2 * self._cap if key == self._key else 0, 64)
         self._graphs.clear()                        # pointers below are baked into captured graphs
+        self._uses_w5b.clear()
         self._pool = None
         self._key, self._cap = key, cap
         sb = self.subbatch_size
@@ -103,6 +105,13 @@ class VideoTrainer:
             self.eager_steps += 1
             return
         g = self._graphs.get(n)
+        if g is not None and self._uses_w5b.get(n) and m._w5b_version != m._w5_version():
+            # the captured graph reads the bf16 copy of linear5.weight and keeps it fresh through its own fused Adam, but holds
+            # no cast node: a writer outside the graph since the last step (load_state_dict, a stock optimizer, an in-place
+            # edit) has left the copy stale. One eager step re-casts it (AVM._w5_bf16) and re-validates the stamp.
+            self._sub_step(n)
+            self.eager_steps += 1
+            return
         if g is None:
             if n not in self._seen:                 # first step of this size: eager (allocates Adam state, operand buffers)
                 self._seen.add(n)
@@ -123,6 +132,7 @@ class VideoTrainer:
             for i, v in zip((1, 2, 3), nbt):
                 getattr(m.visbl, f"bnorm{i}").num_batches_tracked.fill_(v)
             self._graphs[n] = g
+            self._uses_w5b[n] = m._w5b is not None and m._w5b_version == m._w5_version() and m.last_used_w5b
         g.replay()
         self._host_bookkeeping_after_replay()
         self.replays += 1

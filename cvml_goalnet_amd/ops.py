@@ -477,13 +477,14 @@ def counter_add(counter, delta):
     check(lib().goalnet_counter_add(_ctr(counter), int(delta), _s()), "counter_add")
 
 
-def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p):
-    """dst: flat fp32 buffer of n*sum(widths); returns the per-layer (n, width) views."""
+def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p, row_offset=0):
+    """dst: flat fp32 buffer of n*sum(widths); returns the per-layer (n, width) views. row_offset: the masks are rows
+    [row_offset, row_offset + n) of the (row_offset + n, width) masks the same stream yields (data-parallel shards)."""
     _chk(dst)
     total = n * sum(widths)
     assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() == total
     arr = (ctypes.c_int * len(widths))(*widths)
-    check(lib().goalnet_dropout_masks_dev(dst.data_ptr(), n, arr, len(widths), seed, tid_base, tid_stride, _ctr(step), p, _s()),
+    check(lib().goalnet_dropout_masks_dev(dst.data_ptr(), n, arr, len(widths), seed, tid_base, tid_stride, _ctr(step), p, int(row_offset), _s()),
           "dropout_masks_dev")
     out, off = [], 0
     for wdt in widths:

@@ -230,6 +230,11 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 
 /* ---- optimizer: torch.optim.Adam defaults over a flat arena.  main.py:70, 193 ------------------- */
 /* g is scaled by grad_scale first (1/world_size after a SUM all-reduce). `step` is 1-based. */
+/* ---- dispatch introspection (no launch): the kernel template goalnet_conv3x3_fwd / goalnet_conv3x3_fwd_bf16p(_o16) select for
+ * these dims, as a compiler-spelled string ("... [AL = ..., BL = ...]"). bench.py labels its roofline object with it. */
+const char* goalnet_conv3x3_fwd_kernel_name(int N, int H, int W, int Cin, int Cout, int affine);
+const char* goalnet_conv3x3_fwd_bf16p_kernel_name(int N, int H, int W, int Cin, int Cout, int forward);
+
 int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                       double beta2, double eps, int step, float grad_scale, void* stream);
 
@@ -241,9 +246,11 @@ int goalnet_counter_add(int64_t* counter, int64_t delta, void* stream);
 /* counters[i] += d_i for four consecutive counters (adam step, dropout draw, frame cursor, sub-batch index): one launch */
 int goalnet_counters_add4(int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3, void* stream);
 /* `layers` masks back to back in dst: mask l is (n, widths[l]) row-major, drawn from stream
- * tid_base + tid_stride * (*step) + l — the same bits as goalnet_dropout_mask with that tensor_id. widths: host array. */
+ * tid_base + tid_stride * (*step) + l — the same bits as goalnet_dropout_mask with that tensor_id. widths: host array.
+ * row_offset >= 0: mask l holds rows [row_offset, row_offset + n) of the (row_offset + n, widths[l]) mask of that stream, so
+ * that data-parallel ranks draw disjoint rows of the mask one process would draw for the concatenated batch. */
 int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, uint64_t seed, uint32_t tid_base,
-                              uint32_t tid_stride, const int64_t* step, float p, void* stream);
+                              uint32_t tid_stride, const int64_t* step, float p, int64_t row_offset, void* stream);
 /* goalnet_adam_step with the 1-based step count = *step + step_bias (bias 1: the counter holds the completed steps) */
 int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                           double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* stream);

@@ -1,4 +1,5 @@
 // Probe of ds_read_b64_tr_b16 semantics on gfx950: which element does each lane receive?
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O2 -o /tmp/tr_probe scripts/probe/tr_probe.hip && /tmp/tr_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short s16x4 __attribute__((ext_vector_type(4)));

@@ -5,7 +5,7 @@
    profiles/conv_fwd_traffic.json   HBM bytes per launch of the dominant kernel, read by bench.py (roofline.traffic)
 HBM bytes follow MI355X_MICROARCH.md "HBM": bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE reports exactly
 half of a wide coalesced read stream on gfx950, WRITE_SIZE is exact for 16-B-per-lane streaming stores."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -76,7 +76,11 @@ if agg:
             continue
         v = agg[key]
         fe = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]); wr = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+        sys.path.insert(0, ROOT)
+        import bench                                   # kernel_sources_sha: bench.py reports the traffic only while it still matches
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
         json.dump({"kernel": key, "launches": len(v["FETCH_SIZE"]), "fetch_size_kib_avg": fe, "write_size_kib_avg": wr,
-                   "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "source": f"profiles/{tag}_traffic.md"},
+                   "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "source": f"profiles/{tag}_traffic.md",
+                   "sources_sha256": bench.kernel_sources_sha(dt), "git_head": head},
                   open(os.path.join(out, f"conv_fwd_traffic_{dt}.json"), "w"), indent=1)
     print("wrote", f"{tag}_traffic.md")

@@ -22,7 +22,7 @@ DEV = "cuda:0"
 
 def load_model(h, audio, bins=30, dropout="device"):
     params = synth.make_params(h, h, bins, audio)
-    m = AVM(audio_included=audio, device=DEV)
+    m = AVM(audio_included=audio, device=DEV, seed=synth.BASE_SEED)
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
     sd.update(avm_ref.init_buffers())
     m.load_state_dict(sd)
@@ -229,6 +229,7 @@ def test_dropin_surface_cpu_tensors_autograd_and_stock_adam(audio):
     """The reference's own call sequence (main.py:64-70, 187-196) with CPU tensors, vs the oracle."""
     n, h = 10, 40
     model = AVM(audio_included=audio)                                   # main.py:64
+    model.dropout_seed = synth.BASE_SEED                                 # the oracle side regenerates the masks from this seed
     optimizer = torch.optim.Adam(params=model.parameters(), lr=0.001)    # main.py:70, BEFORE any forward
     params = synth.make_params(h, h, 30, audio)
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
@@ -354,7 +355,7 @@ def test_bf16_mode_logits_within_1e3_and_gradients_track_the_oracle():
     themselves are checked to 5e-6 against fp64 on bf16-rounded operands in tests/test_gpu_ops.py."""
     n, h = 16, 40
     params = synth.make_params(h, h, 30, True)
-    model = AVM(audio_included=True, device=DEV, precision="bf16")
+    model = AVM(audio_included=True, device=DEV, precision="bf16", seed=synth.BASE_SEED)
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
     sd.update(avm_ref.init_buffers())
     model.load_state_dict(sd)
@@ -414,3 +415,39 @@ def test_bf16_weight_shadow_follows_every_writer_of_the_arena():
     fresh = a._w5_bf16(a._w5b.numel() // 512)
     assert not torch.equal(before, fresh)
     assert torch.equal(fresh, a._pflat("visbl.linear5.weight").to(torch.bfloat16))
+
+
+def test_bf16_mode_on_frames_wider_than_the_fused_backward_serves():
+    """precision="bf16" on 40 x 430 frames: the conv outputs of blocks 2 and 3 are 143 / 141 pixels wide, beyond the 138 the
+    fused bf16 BatchNorm/pool backward holds in LDS — forward and backward must take the fp32 kernels for those blocks
+    (the reference's Lazy layers accept any size) instead of failing after the forward."""
+    n, h, w = 4, 40, 430
+    torch.manual_seed(5)
+    model = AVM(audio_included=True, device=DEV, precision="bf16", seed=synth.BASE_SEED)
+    model.keep_ctx = True
+    vis = torch.from_numpy(synth.make_visual(n, h, w))
+    aud = torch.from_numpy(synth.make_audio(n))
+    lab = torch.from_numpy(synth.make_labels(n))
+    (_, _), (_, wp1), (_, wp2), (hp3, wp3) = model._sizes(h, w)
+    assert not AVM._bwd16_ok(wp1) and not AVM._bwd16_ok(wp2)
+    model._materialize(hp3 * wp3, 8)
+    sd = model.state_dict()
+    p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    b = {k: v.clone() for k, v in sd.items() if k not in p}
+    loss, pred = model.train_step(aud.to(DEV), vis.to(DEV), lab.to(DEV))
+    torch.cuda.synchronize()
+    taps = hip_taps(model.last_ctx)
+    masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, step=0)]
+    inter = {}
+    with torch.no_grad():
+        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, aud, vis, masks, True, inter)
+    e = (model.last_logit.cpu() - inter["logit"].view(-1)).abs().max().item()
+    print(f"[parity] bf16 mode, 40x430 frames: logit max error {e:.2e}")
+    assert e <= 1e-3
+    o_loss, o_pred, o_g = avm_ref.train_step(p, b, {}, aud, vis, lab, masks, True, pool_taps=taps)
+    for k, og in o_g.items():
+        if _is_reduction_grad(k):
+            continue
+        mine = model.grad_of(k).cpu().reshape(og.shape)
+        l2 = ((mine - og).norm() / og.norm().clamp_min(1e-30)).item()
+        assert l2 <= 0.15, f"{k}: relative L2 error {l2:.3f}"

@@ -1,0 +1,240 @@
+"""GPU: parity of the path `bench.py` times — at the sizes it times — against the CPU oracle (oracle/avm_ref.py).
+
+`bench.py` steps on 1 024 frames of 224 x 224 (64 clips x 16 frames). The oracle needs ~8 s and ~25 GB for a 16-frame
+step at that resolution, so a 1 024-frame oracle step is out of reach; two constructions pin the full-size step anyway:
+
+* **duplicated batch**: 1 024 frames = 64 copies of the same 16 frames (same labels, same dropout masks per copy) have the
+  same BatchNorm batch mean and biased variance as the 16 frames, the same (n, n)-broadcast MSE (`main.py:191`), and — the
+  per-frame dL/dp being 1/64 of the 16-frame one, summed over 64 copies — the same parameter gradients. One 16-frame oracle
+  step therefore pins predictions, loss, every gradient tensor, the updated parameters and the running statistics (unbiased
+  variance factor M/(M-1) recomputed for the larger pixel count) of the N = 1 024 step, while the device runs every
+  > 2^31-element index path, the 256 x 256 tiles, split-K slab counts and grid sizes of the timed configuration.
+* **n = 32 at 224 x 224 and at 40 x 40** (precision="bf16"): n > 16 is where `AVM.forward_device` switches linear5, p3, y3 and
+  the BatchNorm-3 output gradient to their bf16 forms (`bf5 / p16_3 / y16_3 / o16_3`); forward and backward are compared
+  with the oracle under the device's max-pool routing.
+
+Tolerances. fp32: predictions / logits 2e-5 abs, loss 2e-5 rel; every gradient tensor as close to an fp64 run of the oracle
+(same routing) as the oracle's own fp32 arithmetic is (x 4) or within 2e-6 sqrt(copies) of its magnitude — a batch of
+1 024 frames sums 64 x more terms than the 16-frame oracle step, so a fixed relative bound against the fp32 oracle would
+measure the oracle's rounding, not the kernels' (measured: the convolution weight gradients of the 1 024-frame step are 5 x
+CLOSER to the fp64 truth than the oracle's own fp32 arithmetic); updated parameters inside their Adam-sensitivity bound.
+bf16: pre-sigmoid logit max-abs <= 1e-3 vs the fp32 oracle (north star), weight gradients relative L2 <= 0.15.
+Dropout: masks from the seed formula (same bits on both sides); BatchNorm: train mode.
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cvml_goalnet_amd import AVM, ops, synth  # noqa: E402
+from oracle import avm_ref  # noqa: E402
+from test_gpu_avm import NEAR_TIE, _is_reduction_grad, routing_disagreements  # noqa: E402
+
+DEV = "cuda:0"
+LR = 1e-3
+
+
+def _fresh_model(h, precision, seed=7):
+    """random default init on the device (the 224 x 224 model has 1.29 G parameters: never generated on the host)"""
+    torch.manual_seed(seed)
+    m = AVM(audio_included=True, device=DEV, precision=precision)
+    (_, _), _, _, (hp3, wp3) = m._sizes(h, h)
+    m._materialize(hp3 * wp3, 8)
+    return m
+
+
+def _taps_first(ctx, k):
+    """argmax taps of the first k frames as (k, C, Hp, Wp) uint8 CPU tensors (the kernels store [N][C/32][Hp][Wp][32])"""
+    out = {}
+    for i in (1, 2, 3):
+        n, hp, wp, c = ctx[f"idx{i}"].shape
+        raw = ctx[f"idx{i}"].reshape(n, -1)[:k].reshape(k, hp, wp, c)
+        out[i] = ops.idx_to_nhwc(raw, k, hp, wp, c).cpu().permute(0, 3, 1, 2).contiguous()
+    return out
+
+
+def _run_case(precision, h, n_unique, copies):
+    n = n_unique * copies
+    model = _fresh_model(h, precision)
+    model.keep_ctx = True
+    sd0 = model.state_dict()                                           # torch-native layouts, CPU, BEFORE the step
+    p = {k: v for k, v in sd0.items() if v.is_floating_point() and "running" not in k}
+    b = {k: v.clone() for k, v in sd0.items() if k not in p}
+    vis = torch.from_numpy(synth.make_visual(n_unique, h, h))
+    aud = torch.from_numpy(synth.make_audio(n_unique))
+    lab = torch.from_numpy(synth.make_labels(n_unique))
+    masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n_unique, step=0)]
+    model.set_dropout_masks([m.repeat(copies, 1) for m in masks])
+    visg = vis.to(DEV).repeat(copies, 1, 1, 1)
+    audg = aud.to(DEV).repeat(copies, 1, 1)
+    labg = lab.to(DEV).repeat(copies)
+    loss, pred = model.train_step(audg, visg, labg)
+    torch.cuda.synchronize()
+    ctx = model.last_ctx
+    model.last_ctx = None
+    # every copy of a frame must have gone through bit-identical arithmetic (same K order for every GEMM row)
+    pr = pred.view(copies, n_unique)
+    assert torch.equal(pr, pr[:1].expand_as(pr)), "copies of the same frame produced different predictions"
+    for i in (1, 2, 3):
+        raw = ctx[f"idx{i}"].reshape(copies, n_unique, -1)
+        for c in {0, copies // 2, copies - 1}:
+            assert torch.equal(raw[c], raw[0]), f"block {i}: copy {c} routed its max-pool differently from copy 0"
+    taps = _taps_first(ctx, n_unique)
+    logit = model.last_logit[:n_unique].cpu()
+    del ctx, visg, audg
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    # ---- oracle: forward with its own routing (logits, routing check), then the train step under the device's routing
+    inter = {}
+    with torch.no_grad():
+        avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, aud, vis, masks, True, inter)
+    ref_logit = inter["logit"].view(-1).clone()
+    nd, worst = routing_disagreements(inter, taps)
+    del inter
+    gc.collect()
+    e_logit = (logit - ref_logit).abs()
+    print(f"[parity] {precision} {n}x{h}x{h} ({copies} x {n_unique}): logit error vs CPU oracle mean {e_logit.mean():.2e} max {e_logit.max():.2e}; "
+          f"{nd} max-pool windows routed differently (largest top-2 gap {worst:.2e} of max|y|)")
+    fp32 = precision == "fp32"
+    if fp32:
+        assert worst <= NEAR_TIE, "max-pool argmax differs from ATen's where the window is NOT a near-tie"
+        if nd == 0:
+            assert e_logit.max().item() <= 2e-5
+    else:
+        assert e_logit.max().item() <= 1e-3, "bf16 logits outside the north-star tolerance"
+    g64 = None
+    if fp32:
+        # fp64 run of the oracle under the same routing = the truth both fp32 implementations are measured against
+        # (tests/test_gpu_avm.py::test_gradients_within_reference_rounding_of_fp64_truth, here at the bench's size)
+        p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+        pred64 = avm_ref.forward(p64, avm_ref.init_buffers(torch.float64), aud.double(), vis.double(), [m.double() for m in masks], True,
+                                 None, pool_taps=taps)
+        avm_ref.mse_bcast(pred64, lab.double()).backward()
+        g64 = {k: v.grad for k, v in p64.items()}
+        pred64 = pred64.detach()
+        del p64
+        gc.collect()
+    state = {}
+    o_loss, o_pred, o_g = avm_ref.train_step(p, b, state, aud, vis, lab, masks, True, pool_taps=taps)
+    perr = (pred[:n_unique].cpu().view(-1, 1) - o_pred).abs().max().item()
+    lerr = abs(loss.item() - o_loss.item()) / max(1.0, abs(o_loss.item()))
+    print(f"[parity] {precision} {n}x{h}x{h}: |pred - oracle| {perr:.2e}, loss rel err {lerr:.2e} (same routing)")
+    assert perr <= (2e-5 if fp32 else 4e-3) and lerr <= (2e-5 if fp32 else 4e-3)
+    if fp32:
+        e_ref = (o_pred.double() - pred64).abs().max().item()
+        e_hip = (pred[:n_unique].cpu().double().view(-1, 1) - pred64).abs().max().item()
+        print(f"[parity] fp64 truth: pred error oracle-fp32 {e_ref:.2e}, HIP {e_hip:.2e}")
+        assert e_hip <= max(4 * e_ref, 2e-6)
+
+    sd1 = model.state_dict()
+    failures, report = [], []
+    for name, og in o_g.items():
+        mine = model.grad_of(name).cpu().reshape(og.shape)
+        scale = max(og.abs().max().item(), 1e-30)
+        if fp32:
+            # as close to the fp64 truth as the reference's own fp32 arithmetic is (x 4), or within 2e-6 sqrt(copies) of the
+            # tensor's magnitude: the device's fp32 sums over the batch run over `copies` x more terms than the oracle's
+            t = g64.pop(name)
+            e_ref = (og.double() - t).abs().max().item()
+            e_hip = (mine.double() - t).abs().max().item()
+            del t
+            print(f"[parity] fp64 truth: {name:26s} max|g| {scale:.2e}  err oracle-fp32 {e_ref:.2e}  HIP {e_hip:.2e}")
+            if e_hip > max(4 * e_ref, 2e-6 * copies ** 0.5 * scale):
+                failures.append(f"{name}: HIP gradient is {e_hip:.3e} from the fp64 truth, the oracle's fp32 path {e_ref:.3e} (max|g| {scale:.3e})")
+        gerr = mine.sub_(og).abs_()
+        e = gerr.max().item()
+        report.append((e / scale, name))
+        if fp32:
+            # Adam sensitivity: lr * |dg| / (|g| + eps), at most 2 lr (tests/test_gpu_avm.py)
+            bound = gerr.mul_(8.0).div_(og.abs().add_(1e-8)).clamp_(max=2.0).mul_(LR).add_(2e-6)
+            over = (sd1[name] - p[name]).abs_().sub_(bound).max().item()
+            if over > 0:
+                failures.append(f"{name}: after Adam exceeds its sensitivity bound vs oracle by {over:.3e}")
+            del bound
+        elif not _is_reduction_grad(name):
+            l2 = (gerr.double().pow_(2).sum().sqrt() / og.double().norm().clamp_min(1e-30)).item()
+            report[-1] = (l2, name + " [relative L2]")
+            if l2 > 0.15:
+                failures.append(f"{name}: bf16-mode gradient relative L2 error {l2:.3f} > 0.15")
+        del mine, gerr
+    # running statistics: same batch mean; unbiased variance uses the device's (larger) pixel count
+    sizes = model._sizes(h, h)
+    for i in (1, 2, 3):
+        hp, wp = sizes[i]
+        m_dev, m_ora = n * hp * wp, n_unique * hp * wp
+        rm, rv = sd1[f"visbl.bnorm{i}.running_mean"], sd1[f"visbl.bnorm{i}.running_var"]
+        o_rm, o_rv = b[f"visbl.bnorm{i}.running_mean"], b[f"visbl.bnorm{i}.running_var"]
+        var_biased = (o_rv.double() - 0.9) / 0.1 * (m_ora - 1) / m_ora
+        want_rv = 0.9 + 0.1 * var_biased * m_dev / (m_dev - 1)
+        tol = 1e-5 if fp32 else 4e-3
+        if not torch.allclose(rm.double(), o_rm.double(), rtol=tol, atol=tol * o_rm.abs().max().item()):
+            failures.append(f"bnorm{i}.running_mean differs from oracle")
+        if not torch.allclose(rv.double(), want_rv, rtol=tol, atol=1e-7):
+            failures.append(f"bnorm{i}.running_var differs from oracle (unbiased factor for {m_dev} pixels)")
+        assert int(sd1[f"visbl.bnorm{i}.num_batches_tracked"]) == 1
+    report.sort(reverse=True)
+    for e, k in report[:6]:
+        print(f"[parity]     {e:.3e}  {k}")
+    assert not failures, "\n".join(failures)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bench_step_1024_frames_of_224_as_64_copies_of_a_16_frame_oracle_step(precision):
+    """the configuration bench.py times (BASELINE.json metric): 64 clips x 16 frames of 224 x 224"""
+    _run_case(precision, 224, 16, 64)
+
+
+@pytest.mark.parametrize("h", [224, 40])
+def test_bf16_step_of_32_frames_forward_and_backward_vs_oracle(h):
+    """n > 16: linear5 / p3 / y3 / dbn3 on their bf16 forms (avm.py forward_device: bf5, p16_3, y16_3; backward: o16_3)"""
+    _run_case("bf16", h, 32, 1)
+
+
+def test_fp32_step_of_128_frames_of_224_as_8_copies(monkeypatch):
+    """BASELINE.json config 2's size (batch 8 clips = 128 frames, fp32, 1 GPU) on the fp32 engine"""
+    _run_case("fp32", 224, 16, 8)
+
+
+def test_bf16_logits_track_the_oracle_over_25_adam_steps_at_224():
+    """25 fused bf16 train steps on 32 frames of 224 x 224 (n > 16: the bf16 linear5 / p3 branches), probing the forward on
+    the current weights against the fp32 CPU oracle ON THOSE SAME WEIGHTS after 0, 5 and 25 steps. Adam moves every one of
+    linear5's 2.5 M input weights per output by ~lr per step, so on the frames being trained the pre-sigmoid logit grows to
+    O(10^2 - 10^3) within a few steps (measured: 530 after 5 steps, 2 500 after 25 — the reference never ran at 224 x 224);
+    an absolute 1e-3 is then below bf16's resolution of the logit itself. Criterion: max-abs error <= 1e-3 while |logit| <= 1
+    (the north star's regime, random-init weights) and <= 1e-3 of max|logit| beyond."""
+    n, h = 32, 224
+    model = _fresh_model(h, "bf16", seed=11)
+    vis = torch.from_numpy(synth.make_visual(n, h, h))
+    aud = torch.from_numpy(synth.make_audio(n))
+    lab = torch.from_numpy(synth.make_labels(n))
+    ag, vg, lg = aud.to(DEV), vis.to(DEV), lab.to(DEV)
+    worst = []
+    for steps_done in (0, 5, 25):
+        while model._adam_t < steps_done:
+            model.train_step(ag, vg, lg)
+        sd = model.state_dict()
+        p = {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+        b = {k: v.clone() for k, v in sd.items() if k not in p}
+        masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, seed=model.dropout_seed, step=model._drop_step)]
+        bn_backup = {k: getattr(*model._module_of(k)).clone() for k in b}
+        with torch.no_grad():
+            model.forward_device(ag, vg, save=False)
+        hip = model.last_logit.cpu()
+        for k, v in bn_backup.items():
+            getattr(*model._module_of(k)).copy_(v)
+        inter = {}
+        with torch.no_grad():
+            avm_ref.forward(p, b, aud, vis, masks, True, inter)
+        ref = inter["logit"].view(-1)
+        d = (hip - ref).abs()
+        scale = max(1.0, ref.abs().max().item())
+        print(f"[parity] bf16, 224x224, n=32, after {steps_done} Adam steps: logit MAE {d.mean():.2e} max {d.max():.2e} "
+              f"(max|logit| {ref.abs().max():.3f}; max error / scale {d.max().item() / scale:.2e})")
+        worst.append(d.max().item() / scale)
+        del sd, p, b, inter
+        gc.collect()
+    assert max(worst) <= 1e-3, worst

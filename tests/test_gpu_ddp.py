@@ -26,7 +26,7 @@ N, H, WORLD = 8, 40, 2
 
 def _model():
     from oracle import avm_ref
-    m = AVM(audio_included=True, device=DEV)
+    m = AVM(audio_included=True, device=DEV, seed=synth.BASE_SEED)
     sd = {k: torch.from_numpy(v) for k, v in synth.make_params(H, H, 30, True).items()}
     sd.update(avm_ref.init_buffers())
     m.load_state_dict(sd)
@@ -46,6 +46,9 @@ def _step(m, shard):
     m.set_dropout_masks(masks)
     loss, pred = m.train_step(aud, vis, lab)
     torch.cuda.synchronize()
+    if m.grad_sync is not None:
+        m.grad_sync.wait_weights()                                     # shard_linear5: the all-gather of the updated slices
+        torch.cuda.synchronize()
     out = {"loss": loss.cpu(), "pred": pred.cpu().reshape(-1), "grad": m._garena.cpu().clone(), "param": m._arena.cpu().clone()}
     out.update({k: v.cpu().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
     return out
@@ -64,6 +67,34 @@ def _worker(rank, port, tmp):
     res["ddp"] = _step(m, shard)
     m = ddp.enable_global_batch(_model())
     res["global"] = _step(m, shard)
+    # ZeRO-1 for linear5.weight: reduce-scatter, Adam on this rank's slice, all-gather of the updated slices
+    m = _model()
+    m.grad_sync = ddp.GradSync(shard_linear5=True)
+    assert m.grad_sync.sharded(m)
+    res["sharded"] = _step(m, shard)
+    res["sharded_state_elems"] = m._adam_m.numel()
+    res["sharded2"] = _step(m, shard)                                  # second step: the gather of step 1 was waited for
+    m = _model()
+    m.grad_sync = ddp.GradSync()
+    _step(m, shard)
+    res["ddp2"] = _step(m, shard)
+    # the same with precision="bf16" at > 16 rows would gather the bf16 copy; covered on the host side (test_host_logic.py)
+    # replicas built from different torch seeds: sync_params makes them one model before the first exchange
+    torch.manual_seed(1000 + rank)
+    m = AVM(audio_included=True, device=DEV)
+    m.grad_sync = ddp.GradSync()
+    aud, vis, lab, _ = _inputs(shard)
+    m.train_step(aud, vis, lab)
+    torch.cuda.synchronize()
+    res["seeds"] = {"param": m._arena.cpu().clone(), "dropout_seed": m.dropout_seed,
+                    "rm": m.visbl.bnorm2.running_mean.cpu().clone()}
+    # bf16-compressed exchange of bucket 1 (an extension, off by default)
+    try:
+        m = _model()
+        m.grad_sync = ddp.GradSync(compress="bf16")
+        res["compress"] = _step(m, shard)
+    except Exception as e:                                             # this gloo build may not reduce bfloat16
+        res["compress"] = repr(e)
     torch.save(res, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -93,6 +124,30 @@ def test_two_rank_train_step_standard_and_global_batch(tmp_path):
     for k in range(WORLD):                                             # forward is the stand-alone one (local statistics)
         assert torch.equal(r[k]["ddp"]["pred"], r[k]["alone"]["pred"]) and torch.equal(r[k]["ddp"]["loss"], r[k]["alone"]["loss"])
     assert not torch.equal(r[0]["alone"]["grad"], r[1]["alone"]["grad"])
+
+    # ---- sharded linear5.weight: same update as the replicated Adam, bit for bit, with 1/world of its optimizer state
+    for step, ref in (("sharded", "ddp"), ("sharded2", "ddp2")):
+        for k in range(WORLD):
+            assert torch.equal(r[k][step]["param"], r[0][ref]["param"]), f"{step}: rank {k} parameters differ from the replicated path"
+            assert torch.equal(r[k][step]["pred"], r[k][ref]["pred"])
+    w5 = ref_model.spec("visbl.linear5.weight")
+    assert r[0]["sharded_state_elems"] == ref_model._arena_numel - w5.numel + w5.numel // WORLD
+    # ---- replicas from different seeds end up identical; their dropout streams differ
+    assert torch.equal(r[0]["seeds"]["param"], r[1]["seeds"]["param"])
+    assert r[0]["seeds"]["dropout_seed"] != r[1]["seeds"]["dropout_seed"]
+    # ---- bf16-compressed exchange: bucket 1 == the bf16-rounded sum of the bf16-rounded local gradients (2^-8 relative)
+    if isinstance(r[0]["compress"], str):
+        print("[ddp] compress='bf16' not exercised: " + r[0]["compress"])
+    else:
+        lo, hi = w5.offset, w5.offset + w5.numel
+        got = r[0]["compress"]["grad"][lo:hi]
+        assert torch.equal(got, r[1]["compress"]["grad"][lo:hi])
+        ssum = want[lo:hi]
+        assert ((got - ssum).abs() <= 2.0 ** -7 * (r[0]["alone"]["grad"][lo:hi].abs() + r[1]["alone"]["grad"][lo:hi].abs()) + 1e-30).all()
+        for s_ in specs:                                              # the other buckets stay exact fp32 sums
+            if s_.name != "visbl.linear5.weight":
+                sl = slice(s_.offset, s_.offset + s_.numel)
+                assert torch.equal(r[0]["compress"]["grad"][sl], r[0]["ddp"]["grad"][sl]), s_.name
 
     # ---- global batch: two ranks == one process on all the frames
     g = [x["global"] for x in r]

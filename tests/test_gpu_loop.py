@@ -23,7 +23,7 @@ LR = 1e-3
 
 def load_model(h, audio, precision="fp32"):
     params = synth.make_params(h, h, 30, audio)
-    m = AVM(audio_included=audio, device=DEV, precision=precision)
+    m = AVM(audio_included=audio, device=DEV, precision=precision, seed=synth.BASE_SEED)
     sd = {k: torch.from_numpy(v) for k, v in params.items()}
     sd.update(avm_ref.init_buffers())
     m.load_state_dict(sd)
@@ -45,6 +45,11 @@ def test_device_counter_kernels_match_their_host_scalar_twins():
         one = ops.dropout_mask(torch.empty(n, wdt, dtype=torch.float32, device=dev), synth.BASE_SEED, synth.TID_DROP + 8 * 3 + l, synth.DROP_P)
         assert torch.equal(got[l], one)
         assert np.array_equal(got[l].cpu().numpy(), ref_np[l])
+    # a data-parallel shard draws ITS rows of the same masks: rows [4, 7) of the 7-row masks
+    got3 = ops.dropout_masks_dev(torch.empty(3 * sum(widths), dtype=torch.float32, device=dev), 3, widths, synth.BASE_SEED,
+                                 synth.TID_DROP, 8, ctr[1], synth.DROP_P, row_offset=4)
+    for l in range(len(widths)):
+        assert torch.equal(got3[l], got[l][4:7])
     # Adam: step read from device == step passed from the host, three steps
     g = torch.Generator().manual_seed(1)
     cnt = 1003
@@ -117,6 +122,39 @@ def test_graph_loop_equals_eager_train_steps_bit_for_bit(audio, precision):
         assert torch.equal(sd_e[k], sd_g[k]), k
     assert graphed._state.tolist()[:2] == [9, 9] and graphed._adam_t == 9 and graphed._drop_step == 9
     assert torch.equal(graphed._adam_m, eager._adam_m) and torch.equal(graphed._adam_v, eager._adam_v)
+
+
+def test_bf16_graph_loop_survives_writers_outside_the_graph():
+    """precision="bf16" with sub-batches of 20 frames (> 16: linear5 reads the bf16 copy of its weights, which a captured
+    graph keeps fresh through its own fused Adam but never re-casts). A load_state_dict between two videos, and an in-place
+    edit of the Parameter, happen outside the graph: the next sub-batch must not run on the stale copy. Compared bit for
+    bit with eager train_step calls subjected to the same writers."""
+    h, sb = 40, 20
+    eager, graphed = load_model(h, True, "bf16"), load_model(h, True, "bf16")
+    tr = VideoTrainer(graphed, subbatch_size=sb, lr=LR)
+    other = {k: torch.from_numpy(v) for k, v in synth.make_params(h, h, 30, True, seed=synth.BASE_SEED + 99).items()}
+    other.update(avm_ref.init_buffers())
+    for vi in range(3):
+        aud, vis, lab = _video(60, h, True, 10 + vi)                      # 3 x 20
+        if vi == 1:
+            for m in (eager, graphed):
+                m.load_state_dict(other)                                  # main.py:66 between two videos
+        if vi == 2:
+            for m in (eager, graphed):
+                with torch.no_grad():
+                    m.visbl.linear5.weight.mul_(0.5)                      # any in-place writer of the Parameter
+        e_loss, e_pred = [], []
+        for a in range(0, 60, sb):
+            loss, pred = eager.train_step(aud[a:a + sb].to(DEV), vis[a:a + sb].to(DEV), lab[a:a + sb].to(DEV), lr=LR)
+            e_loss.append(loss); e_pred.append(pred)
+        losses, preds = tr.train_video(aud, vis, lab)
+        torch.cuda.synchronize()
+        assert torch.equal(losses, torch.cat(e_loss)), f"video {vi}"
+        assert torch.equal(preds, torch.cat(e_pred)), f"video {vi}"
+    assert graphed.last_used_w5b and tr.replays >= 5 and tr.eager_steps == 3      # first step + one re-validating step per writer
+    sd_e, sd_g = eager.state_dict(), graphed.state_dict()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
 
 
 def test_three_graph_driven_steps_reproduce_the_reference_goldens():

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cvml_goalnet_amd import AVM, synth
-from cvml_goalnet_amd.ddp import GradSync, SyncStats, bucket_slices
+from cvml_goalnet_amd.ddp import GradSync, SyncStats, bucket_slices, shard_bounds
 
 
 def test_synth_is_counter_based_and_stable():
@@ -130,3 +130,112 @@ def test_syncstats_collectives_world2_gloo(tmp_path):
         assert (got["rank"], got["world"], got["avg"]) == (rank, 2, 1.0)
         assert torch.equal(got["sum"], torch.arange(6, dtype=torch.float64) * 3 + 2.0 ** -39)
         assert got["cat"].tolist() == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
+
+
+class _BN:
+    def __init__(self, c, fill):
+        self.running_mean = torch.full((c,), float(fill))
+        self.running_var = torch.full((c,), 1.0 + fill)
+        self.num_batches_tracked = torch.tensor(int(fill))
+
+
+class _Vis:
+    pass
+
+
+class _FakeReplica:
+    """what GradSync touches of an AVM, on CPU tensors"""
+
+    def __init__(self, specs, numel, rank):
+        g = torch.Generator().manual_seed(100 + rank)                  # every rank its own "random init"
+        self._specs, self._arena_numel = specs, numel
+        self._arena = torch.rand(numel, generator=g)
+        self._garena = torch.rand(numel, generator=g)
+        self._adam_m = self._adam_v = None
+        self._adam_t, self._drop_step, self._load_count = 3 * rank, 5 * rank, 0
+        self._state = torch.tensor([self._adam_t, self._drop_step, 0, 0])
+        self.dropout_seed = 1234 + rank
+        self.stat_sync = None
+        self.visbl = _Vis()
+        for i, c in ((1, 64), (2, 256), (3, 512)):
+            setattr(self.visbl, f"bnorm{i}", _BN(c, rank + 1))
+        self._w5b, self._w5b_version = None, None
+
+    def _w5_version(self):
+        return (self._arena._version, self._load_count)
+
+
+def _sync_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = AVM(audio_included=True)
+    specs = m._param_specs(81, 8)
+    lo, hi = bucket_slices(specs, m._arena_numel)[1]
+    out = {}
+    # ---- replicas with different initial state -> one model; dropout streams stay per rank
+    fake = _FakeReplica(specs, m._arena_numel, rank)
+    sync = GradSync(shard_linear5=True)
+    sync.ensure_params_synced(fake)
+    out["sync"] = {"arena": fake._arena.clone(), "rm": fake.visbl.bnorm2.running_mean.clone(), "nbt": int(fake.visbl.bnorm3.num_batches_tracked),
+                   "adam_t": fake._adam_t, "drop_step": fake._drop_step, "state": fake._state.clone(), "seed": fake.dropout_seed,
+                   "load_count": fake._load_count}
+    # ---- sharded linear5.weight: reduce(-scatter), "Adam" (p -= g) on the owned slice, all-gather
+    assert sync.sharded(fake)
+    slo, shi = sync.shard_range(fake)
+    local_g = fake._garena.clone()
+    for k in (0, 1, 2):
+        sync.on_bucket(fake, k)
+    scale = sync.finish(fake)
+    before = fake._arena.clone()
+    for a, b in ((0, lo), (slo, shi), (hi, m._arena_numel)):
+        fake._arena[a:b] -= scale * fake._garena[a:b]
+    sync.after_adam(fake, None)
+    sync.wait_weights()
+    out["sharded"] = {"arena": fake._arena.clone(), "before": before, "local_g": local_g, "range": (slo, shi)}
+    # ---- precision="bf16": the bf16 copy is gathered, the fp32 master of foreign slices is stale until gather_master()
+    fake._w5b = fake._arena[lo:hi].to(torch.bfloat16)
+    fake._w5b_version = fake._w5_version()
+    fake._arena[slo:shi] += 1.0 + rank                                  # "Adam" on the owned slice + its bf16 copy
+    fake._w5b[slo - lo:shi - lo] = fake._arena[slo:shi].to(torch.bfloat16)
+    fake._w5b_version = fake._w5_version()
+    sync.after_adam(fake, fake._w5b)
+    sync.wait_weights()
+    stale = fake._arena[lo:hi].clone()
+    assert sync.master_stale
+    sync.gather_master(fake)
+    out["bf16"] = {"shadow": fake._w5b.clone(), "stale": stale, "master": fake._arena[lo:hi].clone(),
+                   "stamp_ok": fake._w5b_version == fake._w5_version(), "still_stale": sync.master_stale}
+    torch.save(out, os.path.join(tmp, f"y{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_param_sync_and_sharded_linear5_world2_gloo(tmp_path):
+    """ddp.GradSync: (1) ranks that built their model from different torch seeds start from rank 0's parameters, buffers
+    and counters, with one dropout stream per rank; (2) shard_linear5 — reduce-scatter, update of the owned slice, all-gather —
+    leaves every rank with the parameters the replicated update gives; (3) with a bf16 copy the gather moves the copy and
+    gather_master() repairs the fp32 master."""
+    import torch.multiprocessing as mp
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"y{k}.pt") for k in (0, 1)]
+    a, b = r[0]["sync"], r[1]["sync"]
+    ref = _FakeReplica(AVM(audio_included=True)._param_specs(81, 8), a["arena"].numel(), 0)
+    assert torch.equal(a["arena"], ref._arena) and torch.equal(b["arena"], ref._arena)
+    assert torch.equal(b["rm"], torch.full((256,), 1.0)) and b["nbt"] == 1
+    assert (b["adam_t"], b["drop_step"], b["state"].tolist()) == (0, 0, [0, 0, 0, 0])
+    assert a["seed"] == 1234 and b["seed"] != a["seed"] and b["load_count"] == 1
+    m = AVM(audio_included=True)
+    specs = m._param_specs(81, 8)
+    lo, hi = bucket_slices(specs, m._arena_numel)[1]
+    assert r[0]["sharded"]["range"] == (lo, lo + (hi - lo) // 2) and r[1]["sharded"]["range"] == (lo + (hi - lo) // 2, hi)
+    want = r[0]["sharded"]["before"] - 0.5 * (r[0]["sharded"]["local_g"] + r[1]["sharded"]["local_g"])
+    for k in (0, 1):
+        assert torch.equal(r[k]["sharded"]["arena"], want), f"rank {k}"
+    for k in (0, 1):
+        x = r[k]["bf16"]
+        assert torch.equal(x["shadow"], r[0]["bf16"]["shadow"]) and torch.equal(x["master"], r[0]["bf16"]["master"])
+        assert torch.equal(x["shadow"], x["master"].to(torch.bfloat16)) and x["stamp_ok"] and not x["still_stale"]
+        assert not torch.equal(x["stale"], x["master"])                 # the foreign slice really was out of date
+    assert shard_bounds(0, 1000, 8, 3) is None and shard_bounds(64, 64 + 8 * 128, 8, 3) == (64 + 3 * 128, 64 + 4 * 128)
