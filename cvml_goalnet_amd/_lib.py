@@ -87,6 +87,13 @@ PROTOTYPES = {
     "goalnet_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, P]),
     "goalnet_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, P]),
     "goalnet_mse_bcast": (c_int, [P, P, c_int, P, P, P]),
+    "goalnet_cubic_resample": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    "goalnet_logmel_slots": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "goalnet_mfcc_from_logmel": (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, c_int, c_double, P]),
+    "goalnet_cls_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, c_int, P]),
+    "goalnet_cross_entropy": (c_int, [P, P, P, P, c_int, c_int, P]),
+    "goalnet_cls_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, c_int, P]),
+    "goalnet_argmax_plus1": (c_int, [P, P, c_int, c_int, P]),
     "goalnet_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_float, P]),
     "goalnet_counter_add": (c_int, [P, c_int64, P]),
     "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, c_int64, P]),

@@ -71,13 +71,23 @@ class _Spec:
 
 
 class AVM(nn.Module):
-    def __init__(self, audio_included, device=None, seed: Optional[int] = None, precision: str = "fp32"):
+    def __init__(self, audio_included, device=None, seed: Optional[int] = None, precision: str = "fp32", head: str = "regression",
+                 num_classes: int = 5):
         """`seed`: seed of the counter-based dropout stream. None (default) draws it from the torch RNG at construction, so
         dropout follows `torch.manual_seed` as the reference's does (utils.py:170, 245-254 use the global torch RNG) and two
         model instances / two runs do not replay the same masks; parity tests pass synth.BASE_SEED to regenerate the masks
         from the seed formula on the CPU side."""
         super().__init__()
         self.audio_included = audio_included                      # utils.py:235
+        # head="classifier" (EXTENSION): the reference's commented-out variant — Linear(128 -> C), Softmax(dim=1) in place of
+        # the Sigmoid (utils.py:257), then 4y+1 (utils.py:270); trained with CrossEntropyLoss on labels-1 (main.py:69, 189),
+        # predictions = argmax + 1 (main.py:190). forward returns the (N, C) class scores.
+        if head not in ("regression", "classifier"):
+            raise ValueError("head must be 'regression' (the reference's live code) or 'classifier' (its commented-out variant)")
+        if not 2 <= num_classes <= 8:
+            raise ValueError("num_classes must be in 2..8")
+        self.head = head
+        self.num_classes = num_classes if head == "classifier" else 1
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 MFMA contractions)")
         # "bf16": the dense contractions (conv2/conv3 forward + data gradient, linear5 forward) run on the bf16 matrix
@@ -143,7 +153,7 @@ class AVM(nn.Module):
             S.append(_Spec(name + ".weight", kind, (out, inn), inn))
             S.append(_Spec(name + ".bias", "plain", (out,), inn))
 
-        lin("fusion.12", 1, 128); lin("fusion.9", 128, 256); lin("fusion.6", 256, 512)
+        lin("fusion.12", self.num_classes, 128); lin("fusion.9", 128, 256); lin("fusion.6", 256, 512)
         lin("fusion.3", 512, 512); lin("fusion.0", 512, f0_in)
         if self.audio_included:
             lin("audbl.linear3", 128, 128 * l2)
@@ -547,9 +557,14 @@ class AVM(nn.Module):
                            dropmask=masks[1 + li], mult_out=m)
             hs.append(hnext); ms.append(m)
             x = hnext
-        logit = torch.empty(n, dtype=F32, device=dev)
-        out = torch.empty(n, dtype=F32, device=dev)
-        ops.head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
+        if self.head == "classifier":
+            logit = torch.empty(n, self.num_classes, dtype=F32, device=dev)
+            out = torch.empty(n, self.num_classes, dtype=F32, device=dev)          # class scores 4 softmax(z) + 1
+            ops.cls_head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
+        else:
+            logit = torch.empty(n, dtype=F32, device=dev)
+            out = torch.empty(n, dtype=F32, device=dev)
+            ops.head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
         if save:
             ctx.update(p1=p1, idx1=idx1, st1=st1, p2=p2, idx2=idx2, st2=st2, p3=p3, idx3=idx3, st3=st3,
                        a1=a1, a2=a2, hs=hs, ms=ms, logit=logit, out=out, l1=l1, l2=l2)
@@ -603,7 +618,11 @@ class AVM(nn.Module):
 
         # head + fusion MLP (reverse of utils.py:242-258)
         dz = torch.empty(n, 128, dtype=F32, device=dev)
-        ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
+        if self.head == "classifier":
+            ops.cls_head_bwd(dout.view(n, self.num_classes), ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz,
+                             G("fusion.12.weight"), G("fusion.12.bias"))
+        else:
+            ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
         for key, li in (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
             x_in, m_in = hs[li], ms[li]
             ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"), db=G(f"fusion.{key}.bias"))
@@ -745,7 +764,7 @@ class AVM(nn.Module):
             self._materialize(hp3 * wp3, l2)
         if not need_grad:
             out, _ = self.forward_device(aud, vis, save=False)
-            return out.view(-1, 1).to(src_dev)
+            return out.view(-1, self.num_classes).to(src_dev)
         params = [getattr(*self._module_of(s.name)) for s in self._specs]
         return _AVMFunction.apply(self, aud, vis, src_dev, *params)
 
@@ -760,10 +779,14 @@ class AVM(nn.Module):
             out, ctx = self.forward_device(audio, visual, save=True)
         finally:
             self._defer_tick = False
-        n = out.numel()
+        n = out.shape[0]
         loss = torch.empty(1, dtype=F32, device=self._device)
-        dout = torch.empty(n, dtype=F32, device=self._device)
-        if self.stat_sync is not None:
+        dout = torch.empty(out.shape, dtype=F32, device=self._device)
+        if self.head == "classifier":
+            if self.stat_sync is not None:
+                raise GoalnetError("global-batch mode is defined for the regression head's broadcast MSE only")
+            ops.cross_entropy(out, labels.to(F32), loss, dout)          # main.py:69, 189: CrossEntropyLoss(pred, (labels-1).long())
+        elif self.stat_sync is not None:
             # the (N, N) broadcast couples every prediction with every label of the batch: evaluate it on the rank-ordered
             # concatenation and keep this rank's slice of dL/dp
             gout = torch.empty(n * self.stat_sync.world, dtype=F32, device=self._device)
@@ -824,6 +847,11 @@ class AVM(nn.Module):
         if _tick:
             ops.counter_add(self._state[0], 1)
 
+    def predict_classes(self, scores: torch.Tensor) -> torch.Tensor:
+        """head="classifier": `torch.argmax(predictions, axis = 1) + 1` (main.py:97, 190) on the device; (N,) float classes 1..C"""
+        s = scores.detach().to(device=self._device, dtype=F32).contiguous()
+        return ops.argmax_plus1(s, torch.empty(s.shape[0], dtype=F32, device=self._device))
+
     def grad_of(self, name) -> torch.Tensor:
         """Gradient of a parameter as a strided view with the reference's logical shape (linear5: (512, C*HW) copy)."""
         s = self.spec(name)
@@ -844,7 +872,7 @@ class _AVMFunction(torch.autograd.Function):
     def forward(ctx, model, aud, vis, src_dev, *params):
         out, saved = model.forward_device(aud, vis, save=True)
         ctx.model, ctx.saved, ctx.src_dev = model, saved, src_dev
-        return out.view(-1, 1).to(src_dev)
+        return out.view(-1, model.num_classes).to(src_dev)
 
     @staticmethod
     def backward(ctx, gout):

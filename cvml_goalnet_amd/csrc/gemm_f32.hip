@@ -76,16 +76,19 @@ __device__ __forceinline__ uint32_t clamp_u32(int64_t v) {
 // K-contiguous matrix X[rows][K] (leading dim ld < 8M). Optional affine x*scale[k % C] + shift[k % C].
 // Rows past `rows` read 0 (before the affine: with AFFINE they hold `shift`, which only reaches output rows that
 // are never stored).
+// convC > 0: the matrix is a 3x3 convolution's weight [rows][9][convC] read in the (channel chunk, tap) K order of ConvALoader:
+// K-tile kt holds tap kt % 9 of channels [32 (kt / 9), +32).
 template <bool AFFINE>
 struct KCLoader {
     struct P {
         const float* x; int64_t ld; int rows;
         const float* scale; const float* shift; int bnC;
+        int convC;
     };
     static constexpr bool KC = true;
     __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned voff[4], vaff;
-    int bnC;
+    int bnC, convC;
     float4 sc, sh;
     __device__ KCLoader(const P& p, int row0, int tid) {
         const int nrows = p.rows - row0 < BM ? p.rows - row0 : BM;
@@ -95,7 +98,7 @@ struct KCLoader {
             const int rl = (tid >> 3) + 32 * i;
             voff[i] = rl < nrows ? (unsigned)(((int64_t)rl * p.ld + (tid & 7) * 4) * 4) : OOB;
         }
-        bnC = p.bnC;
+        bnC = p.bnC; convC = p.convC;
         if (AFFINE) {
             rsc = make_rsrc(p.scale, (uint32_t)p.bnC * 4);
             rsh = make_rsrc(p.shift, (uint32_t)p.bnC * 4);
@@ -103,7 +106,11 @@ struct KCLoader {
         }
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
-        const unsigned k4 = (unsigned)kt * (BK * 4);
+        unsigned k4 = (unsigned)kt * (BK * 4);
+        if (convC > 0) {
+            const int chunk = kt / 9, tap = kt - 9 * chunk;
+            k4 = (unsigned)(tap * convC + chunk * BK) * 4;
+        }
         if (AFFINE) {
             const unsigned ch4 = (unsigned)((kt * BK) % bnC) * 4;
             sc = bload(rsc, vaff, ch4);
@@ -215,10 +222,12 @@ struct ConvALoader {
             mask[i] = mk;
         }
     }
+    // K order = (32-channel chunk, tap): the nine taps of a chunk re-read the same 128-B lines (one pixel's chunk = one line)
+    // back to back, so they hit L2 instead of streaming the whole halo of the tile nine times (profiles/r02_traffic.md)
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
-        const int k = kt * BK;
-        const int tap = k / C;
-        const int ci = k - tap * C;
+        const int chunk = kt / 9;
+        const int tap = kt - 9 * chunk;
+        const int ci = chunk * BK;
         const int kh = tap / 3, kw = tap - 3 * kh;
         const unsigned s0 = (unsigned)(((kh * W + kw) * C + ci) * 4);     // shift by the resource's W+1 pixel lead
         const unsigned rowstep = (unsigned)(32 * C * 4);
@@ -377,12 +386,24 @@ __device__ __forceinline__ void compute_tile(const float* la, const float* lb, f
 template <class AL, class BL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
-                                                          int ktiles, int ktiles_per_split) {
+                                                          int ktiles, int ktiles_per_split, int xcd_splits) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
     const int tid = threadIdx.x;
-    int tm, tn;
-    tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
-    const int split = blockIdx.y;
+    int tm, tn, split;
+    if (xcd_splits > 0) {
+        // XCD-local split-K: blocks b, b + 8, ... share an XCD (round-robin dispatch) and start in that order, so XCD x walks
+        // splits x, x + 8, ... with ALL output tiles of a split resident together: the split's slice of both operands is
+        // fetched into that XCD's L2 once and re-hit by the other tiles, instead of once per XCD (profiles/r02_traffic.md)
+        const int tiles = tiles_m * tiles_n;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = (j / tiles) * 8 + xcd;
+        if (split >= xcd_splits) return;                  // the grid is padded to whole groups of 8 splits
+        const int t = j - (j / tiles) * tiles;
+        if (m_fast) { tm = t % tiles_m; tn = t / tiles_m; } else { tn = t % tiles_n; tm = t / tiles_n; }
+    } else {
+        tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
+        split = blockIdx.y;
+    }
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles, kt0 + ktiles_per_split);
 
@@ -490,9 +511,12 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
+    // >= 8 splits whose tiles fit an XCD's 64 resident blocks a few times over: XCD-local order (see the kernel)
+    const bool xcd_local = nsplit >= 8 && tiles_m * tiles_n <= 256 && tiles_m * tiles_n * ((nsplit + 7) / 8 * 8) < (1ll << 31);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
+    if (xcd_local) grid = dim3((unsigned)(tiles_m * tiles_n * ((nsplit + 7) / 8 * 8)), 1, 1);
     hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
-                       m_fast, ktiles, kps);
+                       m_fast, ktiles, kps, xcd_local ? nsplit : 0);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
@@ -561,7 +585,7 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
     const int64_t M = (int64_t)N * H * W;
     GN_REQUIRE(M < (1ll << 31) - 256, GOALNET_E_SHAPE, "conv3x3_fwd: N*H*W too large");
     hipStream_t st = (hipStream_t)stream;
-    KCLoader<false>::P bp{w, (int64_t)9 * Cin, Cout, nullptr, nullptr, 1};
+    KCLoader<false>::P bp{w, (int64_t)9 * Cin, Cout, nullptr, nullptr, 1, Cin};
     const EpiP efinal{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
     EpiP ep = efinal;
     const int ktiles = 9 * Cin / BK;
@@ -605,6 +629,7 @@ static int wgrad_splits(int64_t M, int Cin, int Cout) {
     const int64_t smax = ktiles / 4 > 1 ? ktiles / 4 : 1;      // >= 4 K-tiles per split (small sub-batches: few pixels)
     if (s > smax) s = smax;
     if (s > 512) s = 512;
+    if (s >= 8) s = (s + 7) / 8 * 8 <= smax ? (s + 7) / 8 * 8 : s / 8 * 8;      // whole XCD groups (launch_gemm's XCD-local order)
     const int kps = (int)((ktiles + s - 1) / s);
     return (ktiles + kps - 1) / kps;
 }
@@ -688,7 +713,7 @@ int goalnet_linear_fwd(const float* x, int64_t ldx, const float* scale, const fl
     }
     const int nsplit = linear_splits(M, K, J);
     const int ktiles = (int)(K / BK);
-    KCLoader<false>::P bp{w, K, J, nullptr, nullptr, 1};
+    KCLoader<false>::P bp{w, K, J, nullptr, nullptr, 1, 0};
     EpiP ep = efinal;
     if (nsplit > 1) {
         GN_REQUIRE(ws && aligned16(ws), GOALNET_E_WORKSPACE, "linear_fwd: split-K needs a 16-byte aligned workspace");
@@ -697,10 +722,10 @@ int goalnet_linear_fwd(const float* x, int64_t ldx, const float* scale, const fl
     }
     int rc;
     if (scale) {
-        KCLoader<true>::P ap{x, ldx, M, scale, shift, bnC};
+        KCLoader<true>::P ap{x, ldx, M, scale, shift, bnC, 0};
         rc = launch_gemm<KCLoader<true>, KCLoader<false>>("linear_fwd", ap, bp, ep, M, J, ktiles, nsplit, 0, st);
     } else {
-        KCLoader<false>::P ap{x, ldx, M, nullptr, nullptr, 1};
+        KCLoader<false>::P ap{x, ldx, M, nullptr, nullptr, 1, 0};
         rc = launch_gemm<KCLoader<false>, KCLoader<false>>("linear_fwd", ap, bp, ep, M, J, ktiles, nsplit, 0, st);
     }
     if (rc || nsplit == 1) return rc;
@@ -718,7 +743,7 @@ int goalnet_linear_bwd_dx(const float* dy, int64_t lddy, const float* w, const f
     hipStream_t st = (hipStream_t)stream;
     if (M <= SKINNY_MAX_M && (!mult || (aligned16(mult) && ldmult % 4 == 0)))
         return skinny_linear_dx(dy, lddy, w, mult, ldmult, dx, lddx, M, K, J, st);
-    KCLoader<false>::P ap{dy, lddy, M, nullptr, nullptr, 1};
+    KCLoader<false>::P ap{dy, lddy, M, nullptr, nullptr, 1, 0};
     MCLoader<false>::P bp{w, K, (int)K, J, nullptr, nullptr, 1};
     EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};
     return launch_gemm<KCLoader<false>, MCLoader<false>>("linear_bwd_dx", ap, bp, ep, M, K, J / BK, 1, 1, st);

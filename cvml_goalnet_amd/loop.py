@@ -86,6 +86,8 @@ class VideoTrainer:
         ops.rows_copy_batch(segs)                                       # frames[a:b], labels[a:b], audios[a:b]
         # train_step advances all four counters in its last launch: cursor += n, sub-batch index += 1
         loss, pred = m.train_step(aud, vis, lab, self.lr, self.betas, self.eps, _loop_tick=(n, 1))
+        if m.head == "classifier":
+            pred = ops.argmax_plus1(pred, torch.empty(n, dtype=F32, device=dev))        # main.py:190: argmax + 1 is what gets collected
         # predictions.extend(...), losses.append(...) at the positions the step started from
         ops.rows_copy_batch([(self._pred, pred, n, st[2], -n, False), (self._loss, loss, 1, st[3], -1, False)])
 
@@ -151,6 +153,9 @@ class VideoTrainer:
         with torch.no_grad():
             out, _ = m.forward_device(aud, vis, save=False)
         loss = torch.empty(1, dtype=F32, device=m._device)
+        if m.head == "classifier":
+            ops.cross_entropy(out, lab, loss, None)                     # main.py:96-97
+            return loss, ops.argmax_plus1(out, torch.empty(lab.numel(), dtype=F32, device=m._device))
         ops.mse_bcast(out, lab, loss, None)
         return loss, out
 

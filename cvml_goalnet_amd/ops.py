@@ -449,6 +449,41 @@ def head_bwd(dout, out, h, w, mult, dh, dw, db):
           "head_bwd")
 
 
+def cls_head_fwd(h, w, b, logits, scores):
+    """classifier-head extension: scores (N, C) = 4 softmax(h w^T + b) + 1"""
+    _chk(h, w, b, logits, scores)
+    N, K = h.shape
+    C = scores.shape[1]
+    assert w.numel() == C * K and b.numel() == C and scores.is_contiguous() and (logits is None or logits.is_contiguous())
+    check(lib().goalnet_cls_head_fwd(h.data_ptr(), _ld(h), w.data_ptr(), b.data_ptr(), _p(logits), scores.data_ptr(), N, K, C, _s()), "cls_head_fwd")
+
+
+def cross_entropy(scores, labels, loss, dscores):
+    """nn.CrossEntropyLoss()(scores, (labels - 1).long()) and its gradient wrt scores"""
+    _chk(scores, labels, loss, dscores)
+    N, C = scores.shape
+    assert labels.numel() == N and scores.is_contiguous() and (dscores is None or dscores.is_contiguous())
+    check(lib().goalnet_cross_entropy(scores.data_ptr(), labels.data_ptr(), _p(loss), _p(dscores), N, C, _s()), "cross_entropy")
+
+
+def cls_head_bwd(dscores, scores, h, w, mult, dh, dw, db):
+    _chk(dscores, scores, h, w, mult, dh, dw, db)
+    N, K = h.shape
+    C = scores.shape[1]
+    assert dscores.is_contiguous() and scores.is_contiguous() and dw.numel() == C * K and db.numel() == C
+    check(lib().goalnet_cls_head_bwd(dscores.data_ptr(), scores.data_ptr(), h.data_ptr(), _ld(h), w.data_ptr(), _p(mult),
+                                     0 if mult is None else _ld(mult), dh.data_ptr(), _ld(dh), dw.data_ptr(), db.data_ptr(), N, K, C, _s()),
+          "cls_head_bwd")
+
+
+def argmax_plus1(scores, classes):
+    _chk(scores, classes)
+    N, C = scores.shape
+    assert classes.numel() == N and scores.is_contiguous()
+    check(lib().goalnet_argmax_plus1(scores.data_ptr(), classes.data_ptr(), N, C, _s()), "argmax_plus1")
+    return classes
+
+
 def mse_bcast(pred, labels, loss, dpred):
     _chk(pred, labels, loss, dpred)
     N = pred.numel()

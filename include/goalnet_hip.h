@@ -230,6 +230,36 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 
 /* ---- optimizer: torch.optim.Adam defaults over a flat arena.  main.py:70, 193 ------------------- */
 /* g is scaled by grad_scale first (1/world_size after a SUM all-reduce). `step` is 1-based. */
+/* ---- audio pre-processing (/root/reference/utils.py:313-349 from the decoded waveform on) -------------------
+ * y[rows][B] = (float)(R[B][T] . x[rows][T]) in double: the per-row cubic resample of utils.py:337-343 as a matrix (R = the
+ * not-a-knot spline of scipy's interp1d(kind='cubic') evaluated at linspace(0, T-1, B); built on the host). T >= 4. */
+int goalnet_cubic_resample(const float* x, const double* R, float* y, int64_t rows, int T, int B, void* stream);
+/* log-mel power spectrogram in dB (librosa.feature.melspectrogram + power_to_db before its top_db clip, utils.py:333) of
+ * n_slots segments of one waveform: slot s = samples [start[s], start[s] + len[s]); STFT frame t < 1 + len[s] / 512 is the
+ * Hann-windowed 2048 samples centred at t * 512 (zeros outside the segment). logmel: [n_slots][Tmax][128] doubles; window
+ * [2048], twiddle [1024][2] = (cos, -sin)(2 pi k / 2048); mel band m = sum of mel_count[m] bins from mel_start[m] with
+ * weights mel_w[mel_off[m] ...]. */
+int goalnet_logmel_slots(const float* y, const int64_t* start, const int* len, int n_slots, int Tmax, const double* window,
+                         const double* twiddle, const int* mel_start, const int* mel_count, const int* mel_off, const double* mel_w,
+                         double* logmel, void* stream);
+/* per slot: clip at (slot max - top_db), DCT with dct[n_mfcc][128], resample the T = 1 + len/512 columns to B with the
+ * (B, T) matrix at r_all + r_off[slot]: out [n_slots][n_mfcc][B] floats (the (N, 30, B) tensor AudBl takes) */
+int goalnet_mfcc_from_logmel(const double* logmel, const int* len, int n_slots, int Tmax, const double* dct, const double* r_all,
+                             const int64_t* r_off, float* out, int n_mfcc, int B, double top_db, void* stream);
+
+/* ---- classifier-head variant (EXTENSION; comment-only in the reference: /root/reference/utils.py:257 nn.Softmax(dim = 1),
+ * main.py:69 nn.CrossEntropyLoss(), main.py:96, 189 `(labels - 1).long()`, main.py:97, 190 `argmax + 1`) -----------------------
+ * scores (N, C) = 4 softmax(h w^T + b) + 1 (utils.py:270 applies to either head); C <= 8, K < 1024. */
+int goalnet_cls_head_fwd(const float* h, int64_t ldh, const float* w, const float* b, float* logits /* (N,C) or NULL */,
+                         float* scores, int N, int K, int C, void* stream);
+/* loss[0] = mean_n (logsumexp(scores_n) - scores_n[labels_n - 1]) (labels: float classes 1..C); dscores (N, C) or NULL */
+int goalnet_cross_entropy(const float* scores, const float* labels, float* loss /* or NULL */, float* dscores, int N, int C, void* stream);
+/* backward of goalnet_cls_head_fwd: dh = (dz w) * mult, dw[C][K], db[C] with dz = p (.) (4 dscores - <4 dscores, p>), p = (scores-1)/4 */
+int goalnet_cls_head_bwd(const float* dscores, const float* scores, const float* h, int64_t ldh, const float* w, const float* mult,
+                         int64_t ldmult, float* dh, int64_t lddh, float* dw, float* db, int N, int K, int C, void* stream);
+/* classes[n] = (float)(argmax_c scores[n][c] + 1), first maximum on ties (torch.argmax) */
+int goalnet_argmax_plus1(const float* scores, float* classes, int N, int C, void* stream);
+
 /* ---- dispatch introspection (no launch): the kernel template goalnet_conv3x3_fwd / goalnet_conv3x3_fwd_bf16p(_o16) select for
  * these dims, as a compiler-spelled string ("... [AL = ..., BL = ...]"). bench.py labels its roofline object with it. */
 const char* goalnet_conv3x3_fwd_kernel_name(int N, int H, int W, int Cin, int Cout, int affine);

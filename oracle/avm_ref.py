@@ -111,7 +111,7 @@ def _vis_block(x, p, b, i, stride, pad, inter, taps=None):
 
 def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visual,
             drop_masks: Optional[List[torch.Tensor]] = None, audio_included: bool = True,
-            inter: Optional[dict] = None, pool_taps: Optional[dict] = None) -> torch.Tensor:
+            inter: Optional[dict] = None, pool_taps: Optional[dict] = None, head: str = "regression") -> torch.Tensor:
     """AVM.forward(audio_input, visual_input) -> (N,1) in (1,5).  utils.py:260-272.
 
     `b` (BN running stats) is updated in place, as the reference's train-mode forward does even under
@@ -156,7 +156,11 @@ def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visua
             inter[f"fusion.{k + 2}"] = x
     z = F.linear(x, p["fusion.12.weight"], p["fusion.12.bias"])
     if inter is not None:
-        inter["logit"] = z                                    # pre-sigmoid
+        inter["logit"] = z                                    # pre-sigmoid / pre-softmax
+    if head == "classifier":
+        # EXTENSION — the reference's commented-out variant: nn.Softmax(dim = 1) in place of nn.Sigmoid (utils.py:257) on a
+        # Linear(128 -> C); `output = 4 * output + 1` (utils.py:270) is live code and applies to either head
+        return 4 * torch.softmax(z, dim=1) + 1
     return 4 * torch.sigmoid(z) + 1                           # utils.py:270
 
 
@@ -164,6 +168,11 @@ def mse_bcast(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     """nn.MSELoss()(pred(n,1), labels(n,)): broadcast to (n,n), mean over n^2 terms.  main.py:191."""
     d = pred - labels            # (n,1) - (n,) -> (n,n)
     return (d * d).mean()
+
+
+def ce_loss(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """EXTENSION (comment-only in the reference): nn.CrossEntropyLoss()(pred (n,C), (labels - 1).long()).  main.py:69, 96, 189."""
+    return F.cross_entropy(pred, (labels - 1).long())
 
 
 def adam_step(p: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor], state: dict,
@@ -188,11 +197,12 @@ def adam_step(p: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor], state: dic
         w.addcdiv_(m, denom, value=-step_size)
 
 
-def train_step(p, b, state, audio, visual, labels, drop_masks=None, audio_included=True, inter=None, pool_taps=None):
+def train_step(p, b, state, audio, visual, labels, drop_masks=None, audio_included=True, inter=None, pool_taps=None,
+               head="regression"):
     """One sub-batch train step, main.py:187-193. Returns (loss, pred, grads). `p` is updated in place."""
     leaf = {k: v.detach().requires_grad_(True) for k, v in p.items()}
-    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter, pool_taps)
-    loss = mse_bcast(pred, labels)
+    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter, pool_taps, head)
+    loss = ce_loss(pred, labels) if head == "classifier" else mse_bcast(pred, labels)
     names = list(leaf.keys())
     grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
     g = dict(zip(names, grads))

@@ -91,3 +91,33 @@ def test_postproc_quirks_are_reproduced():
     assert postproc_ref.expand_array([1, 2], 3, 8) == [1, 1, 1, 2, 2, 2, 2, 2]
     assert postproc_ref.expand_array([1, 2, 3], 3, 5) == [1, 1, 1, 2, 2]
     assert postproc_ref.expand_array([7, 8], 3, 2) == [7, 8]
+
+
+def test_cubic_resample_restatement_matches_scipy_vectors():
+    """oracle/audio_ref.py's not-a-knot spline matrix vs the vectors `scipy.interpolate.interp1d(kind='cubic')` itself produced
+    (tests/golden/make_golden_audio.py; /root/reference/utils.py:337-343)"""
+    import glob
+    import os
+    from oracle import audio_ref
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample_*.npz")))
+    assert len(files) >= 6
+    for f in files:
+        z = np.load(f, allow_pickle=False)
+        got = audio_ref.cubic_resample(z["rows"], int(z["b"][0]))
+        assert np.abs(got - z["out"]).max() <= 1e-11 * np.abs(z["out"]).max(), f
+    with pytest.raises(ValueError):
+        audio_ref.cubic_resample_matrix(3, 30)
+
+
+def test_audio_restatement_self_consistency():
+    """properties of the (unpinned) MFCC restatement: Parseval for the STFT frame, DCT orthonormality, mel bands of constant
+    energy, slot bounds covering the waveform"""
+    from oracle import audio_ref
+    d = audio_ref.dct_matrix(128, 128)
+    assert np.abs(d @ d.T - np.eye(128)).max() < 1e-12
+    w = audio_ref.mel_filterbank()
+    assert w.shape == (128, 1025) and (w >= 0).all() and (w.sum(axis=1) > 0).all()
+    b = audio_ref.slot_bounds(66250, 3)
+    assert b[0][0] == 0 and b[-1][1] == 66250 and all(x[1] - x[0] == 22083 for x in b)
+    m = audio_ref.mfcc(np.sin(np.arange(22050) * 0.05).astype(np.float32))
+    assert m.shape == (30, 44) and np.isfinite(m).all()
