@@ -37,14 +37,14 @@ PROTOTYPES = {
     "goalnet_conv1_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "goalnet_stat_parts": (c_int, [c_int64]),
     "goalnet_pool_bnstats_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_pool_bnstats_fwd_p16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_pool_bnstats_fwd_p16": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bn_finalize": (c_int, [P, c_int, P, P, P, P, c_float, c_float, c_int64, c_int, P, P, P, P, P]),
     "goalnet_bn_bwd_reduce": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P]),
-    "goalnet_bn_bwd_reduce_t": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int64, c_int, P]),
+    "goalnet_bn_bwd_reduce_t": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int64, c_int, c_int, P]),
     "goalnet_bn_bwd_finalize": (c_int, [P, c_int, P, P, P, c_int64, c_int, P, P, P, P]),
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -53,26 +53,26 @@ PROTOTYPES = {
     "goalnet_conv3x3_fwd_bf16p_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_cast_bf16": (c_int, [P, P, c_int64, P]),
-    "goalnet_cast_f32": (c_int, [P, P, c_int64, P]),
-    "goalnet_bn_apply_bf16": (c_int, [P, P, P, P, c_int64, c_int, P]),
-    "goalnet_bn_apply_bf16_p16": (c_int, [P, P, P, P, c_int64, c_int, P]),
-    "goalnet_conv3x3_fwd_bf16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_cast_bf16": (c_int, [P, P, c_int64, c_int, P]),
+    "goalnet_cast_f32": (c_int, [P, P, c_int64, c_int, P]),
+    "goalnet_bn_apply_bf16": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    "goalnet_bn_apply_bf16_p16": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),
+    "goalnet_conv3x3_fwd_bf16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_linear_fwd_bf16_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
-    "goalnet_linear_fwd_bf16": (c_int, [P, c_int64, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
+    "goalnet_linear_fwd_bf16": (c_int, [P, c_int64, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, c_int, P]),
     "goalnet_bf16_padded_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
-    "goalnet_to_bf16_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_to_bf16_padded_p16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_to_bf16_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_to_bf16_padded_p16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_conv3x3_fwd_bf16p_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_linear_bwd_dx_bf16": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, P]),
+    "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_linear_bwd_dx_bf16": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, c_int, P]),
     "goalnet_linear_bwd_dx_bf16_o16_ok": (c_int, [c_int, c_int64, c_int]),
-    "goalnet_linear_bwd_dx_bf16_o16": (c_int, [P, c_int64, P, P, c_int64, c_int, c_int64, c_int, P]),
+    "goalnet_linear_bwd_dx_bf16_o16": (c_int, [P, c_int64, P, P, c_int64, c_int, c_int64, c_int, c_int, P]),
     "goalnet_conv3x3_fwd_bf16p_o16_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_fwd_bf16p_o16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_linear_bwd_dw_bf16": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int64, c_int, P]),
+    "goalnet_conv3x3_fwd_bf16p_o16": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_linear_bwd_dw_bf16": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int64, c_int, c_int, P]),
     "goalnet_linear_fwd_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "goalnet_linear_fwd": (c_int, [P, c_int64, P, P, c_int, P, P, c_int, P, c_int64, P, c_int64, P, c_int64,
                                    c_int, c_int64, c_int, P, c_size_t, P]),
@@ -99,7 +99,11 @@ PROTOTYPES = {
     "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, c_int64, P]),
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
     "goalnet_adam_step_dev_shadow": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,
-                                             c_int64, P]),
+                                             c_int64, c_int, P]),
+    "goalnet_adam_step_dev_guarded": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,
+                                              c_int64, c_int, P, P]),
+    "goalnet_scale": (c_int, [P, c_int64, c_float, P]),
+    "goalnet_grad_finite_check": (c_int, [P, c_int64, P, c_int64, P, P, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
     "goalnet_frames_preprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),

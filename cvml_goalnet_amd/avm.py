@@ -88,11 +88,20 @@ class AVM(nn.Module):
             raise ValueError("num_classes must be in 2..8")
         self.head = head
         self.num_classes = num_classes if head == "classifier" else 1
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (bf16 MFMA contractions)")
-        # "bf16": the dense contractions (conv2/conv3 forward + data gradient, linear5 forward) run on the bf16 matrix
-        # cores with fp32 accumulation; statistics, master weights, gradients and Adam stay fp32
+        if precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16' or 'fp16' (16-bit MFMA contractions)")
+        # "bf16" / "fp16": the dense contractions (conv2/conv3 forward + data / weight gradient, linear5) run on the 16-bit matrix
+        # cores with fp32 accumulation; statistics, master weights, parameter gradients and Adam stay fp32.
+        # fp16 keeps 11 significand bits against bf16's 8 (~8 x less rounding noise in the logits) but has 5 exponent bits:
+        # the activation gradients it stores need a loss scale (loss_scale, below) and an overflow guard.
         self.precision = precision
+        self._half = precision in ("bf16", "fp16")
+        self._h16 = torch.float16 if precision == "fp16" else torch.bfloat16
+        # dL/dpred is multiplied by loss_scale before backward, the fused Adam divides it out again (a power of two: exact).
+        # 2^12 puts the 16-bit activation gradients of this model (measured: 1e-9 .. 1e-3 at 1 024 frames, scripts/grad_ranges.py)
+        # inside binary16's normal range [6e-5, 65504] with ~2^7 of headroom at the top
+        self.loss_scale = 4096.0 if precision == "fp16" else 1.0
+        self._guard = None             # fp16: int64[2] device counters — step stamped as overflowed, number of skipped updates
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         self._device = torch.device(device) if device is not None else None
@@ -125,6 +134,7 @@ class AVM(nn.Module):
         self._hw3 = self._l2 = None
         self._adam_t = 0
         self._adam_segs = None
+        self._arena_grad_scaled = False    # the gradient arena currently holds loss_scale x gradient (fp16 train_step)
         self._w5b, self._w5b_version = None, None      # bf16 shadow of visbl.linear5.weight and the version stamps it matches
         self._load_count = 0                           # bumped by load_state_dict (its layout kernels write the arena directly)
         self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
@@ -197,6 +207,7 @@ class AVM(nn.Module):
         """Device counters read by the graph-capturable kernels (csrc/stepstate.hip); host mirrors: _adam_t, _drop_step."""
         self._require_device()
         self._state = torch.tensor([self._adam_t, self._drop_step, 0, 0], dtype=torch.int64, device=self._device)
+        self._guard = torch.zeros(2, dtype=torch.int64, device=self._device)
 
     def _materialize(self, hw3: int, l2: int, init: bool = True):
         """Fix the Lazy shapes (first forward or load_state_dict) and build the arena. Parameters are
@@ -372,7 +383,7 @@ class AVM(nn.Module):
         if self.grad_sync is not None and self.grad_sync.master_stale and self._w5b_version != self._w5_version():
             self.grad_sync.gather_master(self)           # the copy is invalid AND foreign slices of the master are stale
         if self._w5b is None or self._w5b.numel() != w5.numel():
-            self._w5b, self._w5b_version = torch.empty(w5.numel(), dtype=torch.bfloat16, device=self._device), None
+            self._w5b, self._w5b_version = torch.empty(w5.numel(), dtype=self._h16, device=self._device), None
         if self._w5b_version != self._w5_version():
             ops.cast_bf16(w5, self._w5b)
             self._w5b_version = self._w5_version()
@@ -389,7 +400,7 @@ class AVM(nn.Module):
         if not hasattr(self, "_padbufs"):
             self._padbufs, self._padgen = {}, {}
         if k not in self._padbufs:
-            self._padbufs[k] = ops.padded_bf16_alloc(n, h, w, c, self._device)
+            self._padbufs[k] = ops.padded_bf16_alloc(n, h, w, c, self._device, dtype=self._h16)
         self._padgen[key] = self._padgen.get(key, 0) + 1      # backward checks that its saved operand was not overwritten
         return self._padbufs[k][1]
 
@@ -433,7 +444,7 @@ class AVM(nn.Module):
         p16: the pooled activation is stored as bf16 (precision="bf16", blocks whose every consumer is a bf16 GEMM pass)."""
         dev = self._device
         assert p16 or y.dtype == F32
-        p = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.bfloat16 if p16 else F32, device=dev)
+        p = torch.empty(n, hc - 2, wc - 2, c, dtype=self._h16 if p16 else F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
         # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
         partials = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=dev)
@@ -479,8 +490,8 @@ class AVM(nn.Module):
         # error more than doubles (MAE 4.7e-5 -> 1.1e-4) and after 7 Adam steps it crosses 1e-3 (3.7e-4 -> 1.1e-3) for 0.6 ms
         p1, idx1, st1 = self._bn_block(y1, n, h1, w1, 64, 1, save)
         del y1          # the conv output is only an input of the pool: backward reads the ReLU mask off p (csrc/pool_bn.hip)
-        bf = self.precision == "bf16"
-        BF16 = torch.bfloat16
+        bf = self._half
+        BF16 = self._h16                 # the 16-bit storage format of this model (bfloat16 or float16)
         # where p is kept in bf16 AND the 256 x 256 tile computes the convolution, the conv output is stored as bf16 too:
         # rounding is monotonic, so the max-pool of the rounded values is the rounded max-pool (same p, same statistics);
         # only ties in the argmax are broken differently
@@ -590,11 +601,11 @@ class AVM(nn.Module):
             ops.bn_bwd_finalize(self._global_sums(partials, 2 * c), self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1],
                                 npix * self.stat_sync.world, c, scratch[:c], scratch[c:], coef3)
         dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)        # dbias partials per (frame, row band)
-        if self.precision == "bf16" and i > 1 and self._bwd16_ok(wc):
+        if self._half and i > 1 and self._bwd16_ok(wc):
             # blocks 2, 3: the only consumers of dy are the bf16 GEMMs -> written once, as bf16, in their padded layout
             dy = self._padbuf(f"dy{i}", n, hc, wc, c)
             ops.bnpool_bwd_bf16p(dbn, p, idx, coef3, None, dy, dparts, n, hc, wc, c)
-        elif self.precision == "bf16" and i > 1:
+        elif self._half and i > 1:
             # frames wider than ~416 px: the rolling LDS rows of the fused bf16 kernel do not fit; fp32 kernel (dz and p are
             # fp32 for such widths, see _p16_ok / backward_device) + one cast pass into the padded layout
             dy32 = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
@@ -652,18 +663,18 @@ class AVM(nn.Module):
         k5 = 512 * hp3 * wp3
         p3f = ctx["p3"].view(n, k5)
         st3 = ctx["st3"]
-        bf = self.precision == "bf16"
-        # precision="bf16": where the 256 x 256 tile serves the data-gradient GEMM, the gradient wrt a BatchNorm output is
+        bf = self._half
+        # precision="bf16" / "fp16": where the 256 x 256 tile serves the data-gradient GEMM, the gradient wrt a BatchNorm output is
         # stored as bf16 (fp32 accumulators rounded once, at the store): its only readers are the two HBM-bound passes of
         # _block_bwd, and the GEMMs behind them consume bf16 anyway
         dz16 = bf and self.grad_bf16
         o16_3 = dz16 and ctx["bf5"] and self._bwd16_ok(wp2) and ops.linear_bwd_dx_bf16_o16_ok(n, k5, 512)
-        dbn3 = torch.empty(n, hp3, wp3, 512, dtype=torch.bfloat16 if o16_3 else F32, device=dev)
+        dbn3 = torch.empty(n, hp3, wp3, 512, dtype=self._h16 if o16_3 else F32, device=dev)
         if bf and ctx["padgen"] != (self._padgen["x1"], self._padgen["x2"]):
             raise RuntimeError("precision='bf16': a second training-mode forward overwrote the saved bf16 operands before "
                                "backward ran; call backward after each forward (as the reference's loop does)")
         if bf and ctx["bf5"]:
-            dz5b = ops.cast_bf16(dz5.contiguous(), torch.empty(n, 512, dtype=torch.bfloat16, device=dev))
+            dz5b = ops.cast_bf16(dz5.contiguous(), torch.empty(n, 512, dtype=self._h16, device=dev))
             ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight"))
             if on_bucket:
                 on_bucket(1)
@@ -691,9 +702,9 @@ class AVM(nn.Module):
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         o16_2 = dz16 and self._bwd16_ok(wp1) and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
-        dbn2 = torch.empty(n, hp2, wp2, 256, dtype=torch.bfloat16 if o16_2 else F32, device=dev)
-        if self.precision == "bf16":
-            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
+        dbn2 = torch.empty(n, hp2, wp2, 256, dtype=self._h16 if o16_2 else F32, device=dev)
+        if self._half:
+            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=self._h16, device=dev))
             if o16_2:
                 self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p_o16,
                             dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
@@ -719,8 +730,8 @@ class AVM(nn.Module):
         wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
-        if self.precision == "bf16":
-            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=torch.bfloat16, device=dev))
+        if self._half:
+            wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=self._h16, device=dev))
             self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_bf16p,
                         dyp2, wtb, None, False, dbn1, n, hp1, wp1, 256, 64)
         else:
@@ -796,11 +807,22 @@ class AVM(nn.Module):
             ops.mse_bcast(out, labels, loss, dout)
         sync = self.grad_sync
         self.last_ctx = ctx if self.keep_ctx else None
+        self._arena_grad_scaled = self.loss_scale != 1.0
+        if self.loss_scale != 1.0:
+            ops.scale_(dout.view(-1), self.loss_scale)      # fp16: every activation gradient downstream carries this factor
         self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)
         scale = 1.0
         if sync is not None:
             scale = sync.finish(self)
-        self.adam_step(lr, betas, eps, scale, _tick=False)
+        guard = None
+        if self.precision == "fp16":
+            # an overflow anywhere in the 16-bit chain reaches the gradients computed last (conv1 ... bnorm3) and first (the
+            # fusion MLP sees nothing 16-bit): checking the two small buckets (after the exchange: all ranks agree) is enough
+            s5 = self.spec("visbl.linear5.weight")
+            after = min(s.offset for s in self._specs if s.offset > s5.offset)
+            ops.grad_finite_check(self._garena[after:], self._state[0], self._guard[0], self._guard[1])
+            guard = self._guard[0]
+        self.adam_step(lr, betas, eps, scale / self.loss_scale, _tick=False, _guard=guard)
         ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
@@ -815,7 +837,7 @@ class AVM(nn.Module):
         slo, shi = sync.shard_range(self)
         return [(0, s5.offset), (slo, shi), (after, self._arena_numel)]
 
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True):
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True, _guard=None):
         """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
         counter state[0] (= completed steps) + 1, so the same captured launch serves every step. With a sharded
         linear5.weight (ddp.py) the pass covers this rank's slice only — three launches — and the optimizer state exists
@@ -836,7 +858,12 @@ class AVM(nn.Module):
             m, v = self._adam_m[off:off + cnt], self._adam_v[off:off + cnt]
             off += cnt
             a, b = max(lo, s5.offset), min(hi, s5.offset + s5.numel)       # the part of linear5.weight inside this segment
-            if shadow_ok and a < b:
+            if _guard is not None:
+                # fp16: the same pass, skipped as a whole when this step's gradients overflowed (goalnet_grad_finite_check)
+                sh = self._w5b[a - s5.offset:b - s5.offset] if (shadow_ok and a < b) else None
+                ops.adam_step_dev_guarded(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0], _guard, shadow=sh,
+                                          shadow_begin=(a - lo) if sh is not None else 0, grad_scale=grad_scale, step_bias=1)
+            elif shadow_ok and a < b:
                 # bf16 mode at > 16 rows: refresh the shadow of linear5.weight in the same pass (the kernels do not bump versions)
                 ops.adam_step_dev_shadow(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0],
                                          self._w5b[a - s5.offset:b - s5.offset], a - lo, grad_scale, step_bias=1)
@@ -856,7 +883,9 @@ class AVM(nn.Module):
         """Gradient of a parameter as a strided view with the reference's logical shape (linear5: (512, C*HW) copy)."""
         s = self.spec(name)
         v = self._view(self._garena, s)
-        return v.reshape(s.shape[0], -1) if s.kind == "lin5" else v
+        v = v.reshape(s.shape[0], -1) if s.kind == "lin5" else v
+        # fp16: train_step leaves loss_scale x gradient in the arena (the fused Adam divides it out); the drop-in path unscales
+        return v / self.loss_scale if (self.loss_scale != 1.0 and self._arena_grad_scaled) else v
 
     def param_of(self, name) -> torch.Tensor:
         s = self.spec(name)
@@ -884,7 +913,12 @@ class _AVMFunction(torch.autograd.Function):
                     prm.grad.untyped_storage().data_ptr() == model._garena.untyped_storage().data_ptr():
                 prm.grad = prm.grad.clone()
         dout = gout.detach().to(device=model._device, dtype=F32).contiguous().view(-1)
+        if model.loss_scale != 1.0:                       # fp16: scaled through the 16-bit chain, unscaled before torch sees .grad
+            dout = ops.scale_(dout.clone(), model.loss_scale)
         model.backward_device(saved, dout)
+        if model.loss_scale != 1.0:
+            ops.scale_(model._garena, 1.0 / model.loss_scale)
+        model._arena_grad_scaled = False
         ctx.saved = None
         grads = [model._view(model._garena, s) for s in model._specs]
         return (None, None, None, None, *grads)

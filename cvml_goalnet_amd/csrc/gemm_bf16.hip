@@ -243,7 +243,7 @@ __device__ __forceinline__ bf16x8 read_frag_h(const char* l, int s, int f, int k
     }
 }
 
-template <bool ATR, bool BTR>
+template <bool ATR, bool BTR, bool F16>
 __device__ __forceinline__ void compute_tile_h(const char* la, const char* lb, f32x16 (&acc)[2][2], int wm, int wn, int lane) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -257,7 +257,11 @@ __device__ __forceinline__ void compute_tile_h(const char* la, const char* lb, f
         for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
             for (int fn = 0; fn < 2; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
+                if constexpr (F16)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[fm]), __builtin_bit_cast(f16x8, b[fn]),
+                                                                        acc[fm][fn], 0, 0, 0);
+                else
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fm], b[fn], acc[fm][fn], 0, 0, 0);
     }
 }
 
@@ -330,7 +334,7 @@ __device__ __forceinline__ void store_acc_h(const EpiP& ep, const f32x16 (&acc)[
         }
 }
 
-template <class AL, class BL>
+template <class AL, class BL, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                            int tiles_m, int tiles_n, int m_fast,
                                                            int ktiles, int ktiles_per_split) {
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
             al.issue(kt + 1, lds[cur ^ 1][0]);
             bl.issue(kt + 1, lds[cur ^ 1][1]);
         }
-        compute_tile_h<AL::TR, BL::TR>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
+        compute_tile_h<AL::TR, BL::TR, F16>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA data has landed before anyone passes the barrier
         __syncthreads();
     }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
 // A short reduction with a huge output (linear5 dW: 16 K-tiles, 5 GB written): the time goes into per-block latency
 // (prologue wait, a DMA round trip per K-tile, the tile store), not into MFMA or LDS. One LDS stage (32 KB) instead of two
 // lets 4 blocks share a CU, which hides those latencies behind each other.
-template <class AL, class BL>
+template <class AL, class BL, bool F16>
 __global__ __launch_bounds__(256, 4) void gemm_bf16_1stage_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                                   int tiles_m, int tiles_n, int m_fast, int ktiles) {
     __shared__ __attribute__((aligned(16))) char lds[2][OP_BYTES];
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_1stage_kernel(typename AL::P
         bl.issue(kt, lds[1]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        compute_tile_h<AL::TR, BL::TR>(lds[0], lds[1], acc, wm, wn, lane);
+        compute_tile_h<AL::TR, BL::TR, F16>(lds[0], lds[1], acc, wm, wn, lane);
         __syncthreads();                                        // everyone has read the tile before it is overwritten
     }
     store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, 0, wm, wn, lane);
@@ -409,83 +413,85 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_1stage_kernel(typename AL::P
 
 template <class AL, class BL>
 int launch_gemm_h_1stage(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
-                         int64_t M, int64_t N, int ktiles, int m_fast, hipStream_t st) {
+                         int64_t M, int64_t N, int ktiles, int m_fast, bool f16, hipStream_t st) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
-    hipLaunchKernelGGL((gemm_bf16_1stage_kernel<AL, BL>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, ap, bp, ep,
-                       (int)tiles_m, (int)tiles_n, m_fast, ktiles);
+    if (f16) hipLaunchKernelGGL((gemm_bf16_1stage_kernel<AL, BL, true>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, ap, bp, ep,
+                                (int)tiles_m, (int)tiles_n, m_fast, ktiles);
+    else hipLaunchKernelGGL((gemm_bf16_1stage_kernel<AL, BL, false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st, ap, bp, ep,
+                            (int)tiles_m, (int)tiles_n, m_fast, ktiles);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
 
 template <class AL, class BL>
 int launch_gemm_h(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
-                  int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, hipStream_t st) {
+                  int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, bool f16, hipStream_t st) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
-    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
-                       ktiles, kps);
+    if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, true>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
+                                ktiles, kps);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, false>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
+                            ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
 
-// ---- fp32 -> bf16 passes (HBM-bound; 8 elements = 32 B in, 16 B out per lane) ---------------------------------------
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
-    return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
-}
-
+// ---- fp32 <-> 16-bit passes (HBM-bound; 8 elements = 32 B in, 16 B out per lane); F16: IEEE fp16 instead of bf16 ----------
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, __hip_bfloat16* __restrict__ y, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
-        reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w)};
+        reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2_h16<F16>(a.x, a.y), pack2_h16<F16>(a.z, a.w), pack2_h16<F16>(b.x, b.y), pack2_h16<F16>(b.z, b.w)};
     }
 }
 
+// 8 consecutive elements of an fp32 or 16-bit tensor as two float4 (H16: the tensor is 16-bit, of format F16)
+template <bool H16, bool F16>
+__device__ __forceinline__ void load8(const void* x, int64_t i, float4& a, float4& b) {
+    if (!H16) {
+        a = reinterpret_cast<const float4*>(x)[2 * i]; b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    } else {
+        const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+        a = make_float4(unpack_lo<F16>(v.x), unpack_hi<F16>(v.x), unpack_lo<F16>(v.y), unpack_hi<F16>(v.y));
+        b = make_float4(unpack_lo<F16>(v.z), unpack_hi<F16>(v.z), unpack_lo<F16>(v.w), unpack_hi<F16>(v.w));
+    }
+}
+
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_f32_kernel(const __hip_bfloat16* __restrict__ x, float* __restrict__ y, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
-        reinterpret_cast<float4*>(y)[2 * i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                                                          __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-        reinterpret_cast<float4*>(y)[2 * i + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
-                                                              __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+        float4 a, b;
+        load8<true, F16>(x, i, a, b);
+        reinterpret_cast<float4*>(y)[2 * i] = a;
+        reinterpret_cast<float4*>(y)[2 * i + 1] = b;
     }
 }
 
-// 8 consecutive elements of an fp32 or bf16 tensor as two float4
-__device__ __forceinline__ void load8(const float* x, int64_t i, float4& a, float4& b) {
-    a = reinterpret_cast<const float4*>(x)[2 * i]; b = reinterpret_cast<const float4*>(x)[2 * i + 1];
-}
-__device__ __forceinline__ void load8(const __hip_bfloat16* x, int64_t i, float4& a, float4& b) {
-    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
-    a = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-    b = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
-}
-
-// y = bf16(x * scale[c] + shift[c]), c = element index mod C (NHWC), C % 8 == 0
-template <typename XT>
-__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const XT* __restrict__ x, const float* __restrict__ scale,
+// y = h16(x * scale[c] + shift[c]), c = element index mod C (NHWC), C % 8 == 0
+template <bool H16, bool F16>
+__global__ __launch_bounds__(256) void bn_apply_bf16_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
                                                            int64_t n8, int C) {
     const int c8n = C >> 3;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c8n) * 8;
         float4 a, b;
-        load8(x, i, a, b);
+        load8<H16, F16>(x, i, a, b);
         const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
         const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
-        reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y)), pack2(fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w)),
-                                               pack2(fmaf(b.x, s1.x, t1.x), fmaf(b.y, s1.y, t1.y)), pack2(fmaf(b.z, s1.z, t1.z), fmaf(b.w, s1.w, t1.w))};
+        reinterpret_cast<u32x4*>(y)[i] = u32x4{pack2_h16<F16>(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y)), pack2_h16<F16>(fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w)),
+                                               pack2_h16<F16>(fmaf(b.x, s1.x, t1.x), fmaf(b.y, s1.y, t1.y)), pack2_h16<F16>(fmaf(b.z, s1.z, t1.z), fmaf(b.w, s1.w, t1.w))};
     }
 }
 
-// x fp32 [N][H][W][C] -> bf16 zero-padded [N][H+2][W+2][C] (interior only; the caller zeroed the buffer once),
+// x fp32 / 16-bit [N][H][W][C] -> 16-bit zero-padded [N][H+2][W+2][C] (interior only; the caller zeroed the buffer once),
 // optional per-channel affine. One thread = 8 channels of one pixel.
-template <typename XT>
-__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const XT* __restrict__ x, const float* __restrict__ scale,
+template <bool H16, bool F16>
+__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, __hip_bfloat16* __restrict__ y,
                                                             int64_t n8, int H, int W, int C) {
     const int c8n = C >> 3;
@@ -498,14 +504,14 @@ __global__ __launch_bounds__(256) void to_bf16_padded_kernel(const XT* __restric
         const int64_t n = t / H;
         const int64_t pm = (n * (H + 2) + h + 1) * (W + 2) + w + 1;
         float4 a, b;
-        load8(x, i, a, b);
+        load8<H16, F16>(x, i, a, b);
         if (scale) {
             const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
             const float4 t0 = *reinterpret_cast<const float4*>(shift + c), t1 = *reinterpret_cast<const float4*>(shift + c + 4);
             a = make_float4(fmaf(a.x, s0.x, t0.x), fmaf(a.y, s0.y, t0.y), fmaf(a.z, s0.z, t0.z), fmaf(a.w, s0.w, t0.w));
             b = make_float4(fmaf(b.x, s1.x, t1.x), fmaf(b.y, s1.y, t1.y), fmaf(b.z, s1.z, t1.z), fmaf(b.w, s1.w, t1.w));
         }
-        *reinterpret_cast<u32x4*>(y + pm * C + c) = u32x4{pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w)};
+        *reinterpret_cast<u32x4*>(y + pm * C + c) = u32x4{pack2_h16<F16>(a.x, a.y), pack2_h16<F16>(a.z, a.w), pack2_h16<F16>(b.x, b.y), pack2_h16<F16>(b.z, b.w)};
     }
 }
 
@@ -520,46 +526,52 @@ unsigned grid1d(int64_t n) {
 
 extern "C" {
 
-int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream) {
+int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, int f16, void* stream) {
     GN_REQUIRE(x && y_bf16, GOALNET_E_NULL, "cast_bf16: null pointer");
     GN_REQUIRE(n > 0 && n % 8 == 0, GOALNET_E_SHAPE, "cast_bf16: element count must be a positive multiple of 8");
     GN_REQUIRE(aligned16(x) && aligned16(y_bf16), GOALNET_E_ALIGN, "cast_bf16: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (__hip_bfloat16*)y_bf16, n / 8);
+    if (f16) hipLaunchKernelGGL(cast_bf16_kernel<true>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (__hip_bfloat16*)y_bf16, n / 8);
+    else hipLaunchKernelGGL(cast_bf16_kernel<false>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (__hip_bfloat16*)y_bf16, n / 8);
     GN_LAUNCH_CHECK("cast_bf16");
     return 0;
 }
 
-int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream) {
+int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, int f16, void* stream) {
     GN_REQUIRE(x_bf16 && y, GOALNET_E_NULL, "cast_f32: null pointer");
     GN_REQUIRE(n > 0 && n % 8 == 0, GOALNET_E_SHAPE, "cast_f32: element count must be a positive multiple of 8");
     GN_REQUIRE(aligned16(x_bf16) && aligned16(y), GOALNET_E_ALIGN, "cast_f32: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(cast_f32_kernel, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)x_bf16, y, n / 8);
+    if (f16) hipLaunchKernelGGL(cast_f32_kernel<true>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)x_bf16, y, n / 8);
+    else hipLaunchKernelGGL(cast_f32_kernel<false>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16*)x_bf16, y, n / 8);
     GN_LAUNCH_CHECK("cast_f32");
     return 0;
 }
 
-int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream) {
+int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, int f16, void* stream) {
     GN_REQUIRE(x && scale && shift && y_bf16, GOALNET_E_NULL, "bn_apply_bf16: null pointer");
     GN_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, GOALNET_E_SHAPE, "bn_apply_bf16: n must be a multiple of C, C of 8");
     GN_REQUIRE(aligned16(x) && aligned16(y_bf16) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "bn_apply_bf16: alignment");
-    hipLaunchKernelGGL(bn_apply_bf16_kernel<float>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                       (__hip_bfloat16*)y_bf16, n / 8, C);
+    if (f16) hipLaunchKernelGGL((bn_apply_bf16_kernel<false, true>), dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const void*)x, scale, shift,
+                                (__hip_bfloat16*)y_bf16, n / 8, C);
+    else hipLaunchKernelGGL((bn_apply_bf16_kernel<false, false>), dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream, (const void*)x, scale, shift,
+                            (__hip_bfloat16*)y_bf16, n / 8, C);
     GN_LAUNCH_CHECK("bn_apply_bf16");
     return 0;
 }
 
-int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream) {
+int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, int f16, void* stream) {
     GN_REQUIRE(x_bf16 && scale && shift && y_bf16, GOALNET_E_NULL, "bn_apply_bf16_p16: null pointer");
     GN_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && n % C == 0, GOALNET_E_SHAPE, "bn_apply_bf16_p16: n must be a multiple of C, C of 8");
     GN_REQUIRE(aligned16(x_bf16) && aligned16(y_bf16) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "bn_apply_bf16_p16: alignment");
-    hipLaunchKernelGGL(bn_apply_bf16_kernel<__hip_bfloat16>, dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)x_bf16, scale, shift, (__hip_bfloat16*)y_bf16, n / 8, C);
+    if (f16) hipLaunchKernelGGL((bn_apply_bf16_kernel<true, true>), dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                                x_bf16, scale, shift, (__hip_bfloat16*)y_bf16, n / 8, C);
+    else hipLaunchKernelGGL((bn_apply_bf16_kernel<true, false>), dim3(grid1d(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                            x_bf16, scale, shift, (__hip_bfloat16*)y_bf16, n / 8, C);
     GN_LAUNCH_CHECK("bn_apply_bf16_p16");
     return 0;
 }
 
 int goalnet_conv3x3_fwd_bf16(const void* x_bf16, const void* w_bf16, const float* bias, int relu, float* y,
-                             int N, int H, int W, int Cin, int Cout, void* stream) {
+                             int N, int H, int W, int Cin, int Cout, int f16, void* stream) {
     GN_REQUIRE(x_bf16 && w_bf16 && y, GOALNET_E_NULL, "conv3x3_fwd_bf16: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16: non-positive dim");
     GN_REQUIRE(Cin % BKH == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16: Cin=%d must be a multiple of %d", Cin, BKH);
@@ -570,7 +582,7 @@ int goalnet_conv3x3_fwd_bf16(const void* x_bf16, const void* w_bf16, const float
     ConvALoaderH::P ap{(const __hip_bfloat16*)x_bf16, H, W, Cin, M};
     KCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, (int64_t)9 * Cin, Cout};
     EpiP ep{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
-    return launch_gemm_h<ConvALoaderH, KCLoaderH>("conv3x3_fwd_bf16", ap, bp, ep, M, Cout, 9 * Cin / BKH, 1, 0, (hipStream_t)stream);
+    return launch_gemm_h<ConvALoaderH, KCLoaderH>("conv3x3_fwd_bf16", ap, bp, ep, M, Cout, 9 * Cin / BKH, 1, 0, f16 != 0, (hipStream_t)stream);
 }
 
 static int linear_splits_h(int M, int64_t K, int J) {
@@ -593,7 +605,7 @@ size_t goalnet_linear_fwd_bf16_ws_bytes(int M, int64_t K, int J) {
 
 int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, const float* bias, int relu,
                             const float* dropmask, int64_t ldmask, float* y, int64_t ldy, float* mult_out, int64_t ldmult,
-                            int M, int64_t K, int J, void* ws, size_t ws_bytes, void* stream) {
+                            int M, int64_t K, int J, void* ws, size_t ws_bytes, int f16, void* stream) {
     GN_REQUIRE(x_bf16 && w_bf16 && y, GOALNET_E_NULL, "linear_fwd_bf16: null pointer");
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 64, GOALNET_E_SHAPE, "linear_fwd_bf16: bad dims");
     GN_REQUIRE(K % BKH == 0 && J % 4 == 0 && ldx % 8 == 0 && ldy % 4 == 0, GOALNET_E_SHAPE, "linear_fwd_bf16: K %% 64, J %% 4, ldx %% 8");
@@ -606,7 +618,7 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
                        "linear_fwd_bf16: workspace too small");
             const EpiP efin{(dropmask || mult_out) ? EPI_FULL : EPI_BIAS_RELU, y, ldy, M, J, bias, relu, dropmask, ldmask, mult_out, ldmult, 0};
             const int rc2 = launch_linear_fwd_bf16_256("linear_fwd_bf16(256)", (const __hip_bfloat16*)x_bf16, ldx, (const __hip_bfloat16*)w_bf16,
-                                                       M, K, J, (float*)ws, ns, st);
+                                                       M, K, J, (float*)ws, ns, f16 != 0, st);
             if (rc2) return rc2;
             return launch_splitk_reduce("linear_fwd_bf16(256).reduce", (const float*)ws, ns, (int64_t)M * J, efin, st);
         }
@@ -621,7 +633,7 @@ int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16,
                    "linear_fwd_bf16: split-K needs a 16-byte aligned workspace of goalnet_linear_fwd_bf16_ws_bytes()");
         ep = EpiP{EPI_RAW, (float*)ws, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
     }
-    const int rc = launch_gemm_h<KCLoaderH, KCLoaderH>("linear_fwd_bf16", ap, bp, ep, M, J, (int)(K / BKH), nsplit, 0, st);
+    const int rc = launch_gemm_h<KCLoaderH, KCLoaderH>("linear_fwd_bf16", ap, bp, ep, M, J, (int)(K / BKH), nsplit, 0, f16 != 0, st);
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("linear_fwd_bf16.reduce", (const float*)ws, nsplit, (int64_t)M * J, efinal, st);
 }
@@ -637,26 +649,30 @@ int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems,
     return 0;
 }
 
-int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream) {
+int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, int f16, void* stream) {
     GN_REQUIRE(x && y_pad, GOALNET_E_NULL, "to_bf16_padded: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "to_bf16_padded: scale/shift must both be set or both NULL");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, GOALNET_E_SHAPE, "to_bf16_padded: bad dims (C %% 8)");
     GN_REQUIRE(aligned16(x) && aligned16(y_pad) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "to_bf16_padded: alignment");
     const int64_t n8 = (int64_t)N * H * W * (C / 8);
-    hipLaunchKernelGGL(to_bf16_padded_kernel<float>, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
-                       (__hip_bfloat16*)y_pad, n8, H, W, C);
+    if (f16) hipLaunchKernelGGL((to_bf16_padded_kernel<false, true>), dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, (const void*)x, scale, shift,
+                                (__hip_bfloat16*)y_pad, n8, H, W, C);
+    else hipLaunchKernelGGL((to_bf16_padded_kernel<false, false>), dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream, (const void*)x, scale, shift,
+                            (__hip_bfloat16*)y_pad, n8, H, W, C);
     GN_LAUNCH_CHECK("to_bf16_padded");
     return 0;
 }
 
-int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream) {
+int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, int f16, void* stream) {
     GN_REQUIRE(x_bf16 && y_pad, GOALNET_E_NULL, "to_bf16_padded_p16: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "to_bf16_padded_p16: scale/shift must both be set or both NULL");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, GOALNET_E_SHAPE, "to_bf16_padded_p16: bad dims (C %% 8)");
     GN_REQUIRE(aligned16(x_bf16) && aligned16(y_pad) && aligned16(scale) && aligned16(shift), GOALNET_E_ALIGN, "to_bf16_padded_p16: alignment");
     const int64_t n8 = (int64_t)N * H * W * (C / 8);
-    hipLaunchKernelGGL(to_bf16_padded_kernel<__hip_bfloat16>, dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)x_bf16, scale, shift, (__hip_bfloat16*)y_pad, n8, H, W, C);
+    if (f16) hipLaunchKernelGGL((to_bf16_padded_kernel<true, true>), dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream,
+                                x_bf16, scale, shift, (__hip_bfloat16*)y_pad, n8, H, W, C);
+    else hipLaunchKernelGGL((to_bf16_padded_kernel<true, false>), dim3(grid1d(n8)), dim3(256), 0, (hipStream_t)stream,
+                            x_bf16, scale, shift, (__hip_bfloat16*)y_pad, n8, H, W, C);
     GN_LAUNCH_CHECK("to_bf16_padded_p16");
     return 0;
 }
@@ -679,7 +695,7 @@ size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout
 }
 
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, int f16, void* stream) {
     GN_REQUIRE(x_pad && w_bf16 && y, GOALNET_E_NULL, "conv3x3_fwd_bf16p: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: non-positive dim");
     GN_REQUIRE(Cin % BKH == 0 && Cout % 4 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p: Cin %% 64, Cout %% 4");
@@ -694,7 +710,7 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
     // large problems: the 256 x 256 phased tile (gemm_bf16_256.hip); GOALNET_BF16_TILE=128 / 256 forces a choice (tests, A/B runs)
     {
         if (conv_use_256(M, Cout)) return launch_conv_bf16_256("conv3x3_fwd_bf16p(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M,
-                                             (const __hip_bfloat16*)w_bf16, Cout, efinal, st);
+                                             (const __hip_bfloat16*)w_bf16, Cout, efinal, f16 != 0, st);
     }
     const int nsplit = ws ? conv_splits_h(M, Cin, Cout) : 1;
     if (nsplit > 1) {
@@ -702,7 +718,7 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
                    "conv3x3_fwd_bf16p: workspace too small or misaligned");
         ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
     }
-    const int rc = launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, st);
+    const int rc = launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, f16 != 0, st);
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("conv3x3_fwd_bf16p.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }
@@ -728,7 +744,7 @@ int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout) {
 /* y_bf16[N][H][W][Cout] = bf16(act(conv3x3(x_pad, w) + bias)): the fp32 accumulator (+ bias, ReLU) is rounded once, at
  * the store. bias NULL, relu 0: the data-gradient use (w = flipped weights). */
 int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const float* bias, int relu, void* y_bf16,
-                                  int N, int H, int W, int Cin, int Cout, void* stream) {
+                                  int N, int H, int W, int Cin, int Cout, int f16, void* stream) {
     GN_REQUIRE(x_pad && w_bf16 && y_bf16, GOALNET_E_NULL, "conv3x3_fwd_bf16p_o16: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: non-positive dim");
     GN_REQUIRE(Cin % BKH == 0 && Cout % 8 == 0, GOALNET_E_SHAPE, "conv3x3_fwd_bf16p_o16: Cin %% 64, Cout %% 8");
@@ -739,7 +755,7 @@ int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const f
                "conv3x3_fwd_bf16p_o16: dims not served (ask goalnet_conv3x3_fwd_bf16p_o16_ok; use goalnet_conv3x3_fwd_bf16p)");
     const EpiP ep{EPI_BIAS_RELU, nullptr, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0, y_bf16};
     return launch_conv_bf16_256("conv3x3_fwd_bf16p_o16(256)", (const __hip_bfloat16*)x_pad, H, W, Cin, M, (const __hip_bfloat16*)w_bf16,
-                                Cout, ep, (hipStream_t)stream);
+                                Cout, ep, f16 != 0, (hipStream_t)stream);
 }
 
 static int wgrad_splits_h(int64_t Mp, int Cin, int Cout) {
@@ -771,7 +787,7 @@ size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cou
 
 /* dw[Cout][3][3][Cin] (fp32) = sum over the padded pixel grid of dy_pad[pm][co] * x_pad[pm + shift(tap)][ci] */
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
-                               int N, int H, int W, int Cin, int Cout, void* stream) {
+                               int N, int H, int W, int Cin, int Cout, int f16, void* stream) {
     GN_REQUIRE(x_pad && dy_pad && dw && ws, GOALNET_E_NULL, "conv3x3_wgrad_bf16: null pointer");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE,
                "conv3x3_wgrad_bf16: channels must be positive multiples of 8");
@@ -784,7 +800,7 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
     if (wgrad_use_256(Mp, Cin, Cout)) {
         const int ns = wgrad_splits_256(Mp, Cin, Cout);
         const int rc = launch_wgrad_bf16_256("conv3x3_wgrad_bf16(256)", (const __hip_bfloat16*)x_pad, (const __hip_bfloat16*)dy_pad, W + 2,
-                                             Cin, Cout, Mp, (float*)ws, ns, st);
+                                             Cin, Cout, Mp, (float*)ws, ns, f16 != 0, st);
         if (rc) return rc;
         EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
         return launch_splitk_reduce("conv3x3_wgrad_bf16(256).reduce", (const float*)ws, ns, slab, er, st);
@@ -794,7 +810,7 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
     MCLoaderH::P ap{(const __hip_bfloat16*)dy_pad, Cout, Cout, (int)Mp};
     ConvWgradBLoaderH::P bp{(const __hip_bfloat16*)x_pad, W + 2, Cin, Mp};
     EpiP ep{EPI_RAW, (float*)ws, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
-    const int rc = launch_gemm_h<MCLoaderH, ConvWgradBLoaderH>("conv3x3_wgrad_bf16", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
+    const int rc = launch_gemm_h<MCLoaderH, ConvWgradBLoaderH>("conv3x3_wgrad_bf16", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, f16 != 0, st);
     if (rc) return rc;
     EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     return launch_splitk_reduce("conv3x3_wgrad_bf16.reduce", (const float*)ws, nsplit, slab, er, st);
@@ -802,18 +818,18 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
 
 /* dx[m][k] = (sum_j dy_bf16[m][j] * w_bf16[j][k]) * mult[m][k]   (fp32 out, mult nullable); J % 64 == 0 */
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
-                               float* dx, int64_t lddx, int M, int64_t K, int J, void* stream) {
+                               float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream) {
     GN_REQUIRE(dy_bf16 && w_bf16 && dx, GOALNET_E_NULL, "linear_bwd_dx_bf16: null pointer");
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: bad dims");
     GN_REQUIRE(J % BKH == 0 && K % 8 == 0 && lddy % 8 == 0 && lddx % 4 == 0, GOALNET_E_SHAPE, "linear_bwd_dx_bf16: J %% 64, K %% 8");
     GN_REQUIRE(aligned16(dy_bf16) && aligned16(w_bf16) && aligned16(dx), GOALNET_E_ALIGN, "linear_bwd_dx_bf16: alignment");
     if (!mult && linear_use_256(M, K, J))
         return launch_linear_dx_bf16_256("linear_bwd_dx_bf16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)w_bf16, M, K,
-                                         J, dx, nullptr, lddx, (hipStream_t)stream);
+                                         J, dx, nullptr, lddx, f16 != 0, (hipStream_t)stream);
     KCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)w_bf16, K, (int)K, J};
     EpiP ep{mult ? EPI_MUL : EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, mult, ldmult, nullptr, 0, 0};
-    return launch_gemm_h<KCLoaderH, MCLoaderH>("linear_bwd_dx_bf16", ap, bp, ep, M, K, J / BKH, 1, 1, (hipStream_t)stream);
+    return launch_gemm_h<KCLoaderH, MCLoaderH>("linear_bwd_dx_bf16", ap, bp, ep, M, K, J / BKH, 1, 1, f16 != 0, (hipStream_t)stream);
 }
 
 /* 1 when goalnet_linear_bwd_dx_bf16_o16 serves these dims (the shapes the 256 x 256 tile takes), else 0 */
@@ -823,7 +839,7 @@ int goalnet_linear_bwd_dx_bf16_o16_ok(int M, int64_t K, int J) {
 
 /* dx_bf16[m][k] = bf16(sum_j dy_bf16[m][j] * w_bf16[j][k]): the data gradient rounded once, at the store (fp32 accumulation) */
 int goalnet_linear_bwd_dx_bf16_o16(const void* dy_bf16, int64_t lddy, const void* w_bf16, void* dx_bf16, int64_t lddx,
-                                   int M, int64_t K, int J, void* stream) {
+                                   int M, int64_t K, int J, int f16, void* stream) {
     GN_REQUIRE(dy_bf16 && w_bf16 && dx_bf16, GOALNET_E_NULL, "linear_bwd_dx_bf16_o16: null pointer");
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_bf16_o16: bad dims");
     GN_REQUIRE(J % BKH == 0 && K % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, GOALNET_E_SHAPE, "linear_bwd_dx_bf16_o16: J %% 64, K %% 8, lddx %% 8");
@@ -831,12 +847,12 @@ int goalnet_linear_bwd_dx_bf16_o16(const void* dy_bf16, int64_t lddy, const void
     GN_REQUIRE(goalnet_linear_bwd_dx_bf16_o16_ok(M, K, J), GOALNET_E_SHAPE,
                "linear_bwd_dx_bf16_o16: dims not served (ask goalnet_linear_bwd_dx_bf16_o16_ok; use goalnet_linear_bwd_dx_bf16)");
     return launch_linear_dx_bf16_256("linear_bwd_dx_bf16_o16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)w_bf16, M, K,
-                                     J, nullptr, (__hip_bfloat16*)dx_bf16, lddx, (hipStream_t)stream);
+                                     J, nullptr, (__hip_bfloat16*)dx_bf16, lddx, f16 != 0, (hipStream_t)stream);
 }
 
 /* dw[j][k] = sum_m dy_bf16[m][j] * x_bf16[m][k]   (fp32 out) */
 int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_bf16, int64_t ldx, float* dw,
-                               int M, int64_t K, int J, void* stream) {
+                               int M, int64_t K, int J, int f16, void* stream) {
     GN_REQUIRE(dy_bf16 && x_bf16 && dw, GOALNET_E_NULL, "linear_bwd_dw_bf16: null pointer");
     GN_REQUIRE(M > 0 && J > 0 && K > 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: bad dims");
     GN_REQUIRE(J % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0, GOALNET_E_SHAPE, "linear_bwd_dw_bf16: J, K, lds %% 8");
@@ -846,14 +862,14 @@ int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_
         const char* forced = getenv("GOALNET_BF16_TILE");
         const bool big = forced ? forced[0] == '2' : (J >= 256 && M >= 256 && K >= (1 << 18));
         if (big) return launch_linear_dw_bf16_256("linear_bwd_dw_bf16(256)", (const __hip_bfloat16*)dy_bf16, lddy, (const __hip_bfloat16*)x_bf16,
-                                                  ldx, M, K, J, dw, (hipStream_t)stream);
+                                                  ldx, M, K, J, dw, f16 != 0, (hipStream_t)stream);
     }
     MCLoaderH::P ap{(const __hip_bfloat16*)dy_bf16, lddy, J, M};
     MCLoaderH::P bp{(const __hip_bfloat16*)x_bf16, ldx, (int)K, M};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     // measured at M = 1024, K = 2.5 M: 3.8 ms with one stage and 4 blocks per CU vs 4.7 ms with two stages and 2 (the data
     // gradient, whose W tiles are 256-B pieces 5 MB apart, is the other way round: 10.2 vs 6.6 ms, and keeps two stages)
-    return launch_gemm_h_1stage<MCLoaderH, MCLoaderH>("linear_bwd_dw_bf16", ap, bp, ep, J, K, (M + BKH - 1) / BKH, 1, (hipStream_t)stream);
+    return launch_gemm_h_1stage<MCLoaderH, MCLoaderH>("linear_bwd_dw_bf16", ap, bp, ep, J, K, (M + BKH - 1) / BKH, 1, f16 != 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

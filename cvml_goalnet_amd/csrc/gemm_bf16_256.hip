@@ -250,15 +250,18 @@ __device__ __forceinline__ bf16x8 read_frag(const char* half, int row0, int ks, 
 // reaches the closing barrier while its last MFMAs drain. Hazards the compiler no longer covers are handled here:
 // accumulating back to back into the same registers needs no wait states (CDNA3/4 ISA, XDL write -> XDL SrcC, same
 // vDst); the epilogue reads the accumulators only after an explicit drain (s_nop block after the loop).
+template <bool F16>
 __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    // the two opcodes share operand / accumulator layouts and issue rate; the 16-bit patterns in a, b are read as fp16 or bf16
+    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 #define GN_PHASE(ACC0, ACC1, AF, BF)                                                                        \
     if constexpr (TRA || TRB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* the asm fragment reads (rd_tr) */ \
     asm volatile("s_barrier\n\ts_setprio 1" ::: "memory");                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
-        mfma_pinned(ACC0, AF[0][ks], BF[ks]);                                                               \
-        mfma_pinned(ACC1, AF[1][ks], BF[ks]);                                                               \
+        mfma_pinned<F16>(ACC0, AF[0][ks], BF[ks]);                                                          \
+        mfma_pinned<F16>(ACC1, AF[1][ks], BF[ks]);                                                          \
     }                                                                                                       \
     asm volatile("s_setprio 0\n\ts_barrier" ::: "memory");
 
@@ -272,7 +275,7 @@ __device__ unsigned long long gn_stamps[6 * 65536];
 #endif
 
 // ROLE only separates the symbols (0: convolution forward, 1: data gradient) so that profiles list them apart
-template <class AL, class BL, int ROLE>
+template <class AL, class BL, int ROLE, bool F16>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                               int tiles_m, int tiles_n, int m_fast, int ktiles_total,
                                                               int ktiles_per_split) {
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                             const int g = 2 * gp + k;
                             float n0 = acc[mi][ni][4 * g], n1 = acc[mi][ni][4 * g + 1], n2 = acc[mi][ni][4 * g + 2], n3 = acc[mi][ni][4 * g + 3];
                             quad_transpose4(n0, n1, n2, n3, lane);
-                            pk[k][0] = pack2_bf16(fin(n0), fin(n1));
-                            pk[k][1] = pack2_bf16(fin(n2), fin(n3));
+                            pk[k][0] = pack2_h16<F16>(fin(n0), fin(n1));
+                            pk[k][1] = pack2_h16<F16>(fin(n2), fin(n3));
                         }
                         // lane hi = 0 keeps group 2gp and gets the partner's 2gp (its columns + 4); hi = 1 keeps 2gp + 1
                         const unsigned s0 = hi ? pk[0][0] : pk[1][0], s1 = hi ? pk[0][1] : pk[1][1];
@@ -478,40 +481,47 @@ extern "C" int goalnet_debug_stamps(unsigned long long* host_dst, int nblocks) {
 
 namespace goalnet {
 
-// conv 3x3 forward / data gradient on zero-padded bf16 activations with the 256^2 phased tile; ep.mode RAW or BIAS_RELU
-template <int ROLE>
-static int launch_conv_bf16_256_role(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M,
-                                     const __hip_bfloat16* w, int Cout, const EpiP& ep, hipStream_t st) {
-    typedef ConvAPadLoader256<64> AL;
-    typedef KCLoader256<32> BL;
+// one launch of gemm_bf16_256_kernel<AL, BL, ROLE, F16>: reserves the 128 KB of dynamic LDS once per instantiation
+template <class AL, class BL, int ROLE, bool F16>
+static int launch_256_t(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep, int64_t tiles_m,
+                        int64_t tiles_n, int nsplit, int m_fast, int ktiles, int kps, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, ROLE, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
-    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
-    AL::P ap{x_pad, H, W, Cin, M};
-    BL::P bp{w, (int64_t)9 * Cin, Cout, Cin};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
-                       (int)tiles_m, (int)tiles_n, 0, 9 * Cin / BKH, 9 * Cin / BKH);
+    GN_REQUIRE(tiles_m * tiles_n * nsplit < (1ll << 31), GOALNET_E_SHAPE, "%s: too many blocks", name);
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE, F16>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
+                       ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
-
-template <class AL, class BL, int ROLE> static const char* gemm_bf16_256_kernel_name() { return __PRETTY_FUNCTION__; }
-const char* conv_bf16_256_kernel_name(int role) {
-    return role == 0 ? gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 0>()
-                     : gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 1>();
+template <class AL, class BL, int ROLE>
+static int launch_256(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep, int64_t tiles_m,
+                      int64_t tiles_n, int nsplit, int m_fast, int ktiles, int kps, bool f16, hipStream_t st) {
+    return f16 ? launch_256_t<AL, BL, ROLE, true>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, m_fast, ktiles, kps, st)
+               : launch_256_t<AL, BL, ROLE, false>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, m_fast, ktiles, kps, st);
 }
 
-// conv 3x3 forward (bias + ReLU epilogue) / data gradient (raw epilogue) on zero-padded bf16 activations, 256^2 phased tile
+template <class AL, class BL, int ROLE, bool F16> static const char* gemm_bf16_256_kernel_name() { return __PRETTY_FUNCTION__; }
+const char* conv_bf16_256_kernel_name(int role) {
+    return role == 0 ? gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 0, false>()
+                     : gemm_bf16_256_kernel_name<ConvAPadLoader256<64>, KCLoader256<32>, 1, false>();
+}
+
+// conv 3x3 forward (bias + ReLU epilogue) / data gradient (raw epilogue) on zero-padded 16-bit activations, 256^2 phased tile
 int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w,
-                         int Cout, const EpiP& ep, hipStream_t st) {
+                         int Cout, const EpiP& ep, bool f16, hipStream_t st) {
+    typedef ConvAPadLoader256<64> AL;
+    typedef KCLoader256<32> BL;
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
+    AL::P ap{x_pad, H, W, Cin, M};
+    BL::P bp{w, (int64_t)9 * Cin, Cout, Cin};
+    const int kt = 9 * Cin / BKH;
     // ROLE 0 carries the bias (in its accumulator start) and the optional ReLU; ROLE 1 stores raw accumulators
-    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_conv_bf16_256_role<0>(name, x_pad, H, W, Cin, M, w, Cout, ep, st)
-                                               : launch_conv_bf16_256_role<1>(name, x_pad, H, W, Cin, M, w, Cout, ep, st);
+    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_256<AL, BL, 0>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, f16, st)
+                                                            : launch_256<AL, BL, 1>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, f16, st);
 }
 
 // split count of the weight gradient on 256 x 256 tiles: ~2048 blocks, a whole number of 256-CU rounds where possible
@@ -545,84 +555,49 @@ int linear_fwd_splits_256(int M, int64_t K, int J) {
 
 // y_slabs[split][M][J] (fp32) = partial sums of x[M][K] . w[J][K]^T over the split's K range; the caller reduces + epilogue
 int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_t ldx, const __hip_bfloat16* w, int M, int64_t K,
-                               int J, float* slabs, int nsplit, hipStream_t st) {
+                               int J, float* slabs, int nsplit, bool f16, hipStream_t st) {
     typedef KCLoader256<64> AL;
     typedef KCLoader256<32> BL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (J + T - 1) / T;
     const int ktiles = (int)(K / BKH);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     AL::P ap{x, ldx, M, 0};
     BL::P bp{w, K, J, 0};
     EpiP ep{EPI_RAW, slabs, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 3>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
-                       ap, bp, ep, (int)tiles_m, (int)tiles_n, 1, ktiles, kps);
-    GN_LAUNCH_CHECK(name);
-    return 0;
+    return launch_256<AL, BL, 3>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, f16, st);
 }
 
-// dx[M][K] (fp32) = dy[M][J] . w[J][K]: A K-contiguous (reduction index j), B row-contiguous; no split (J / 64 K-tiles)
+// dx[M][K] (fp32, or 16-bit into dx16) = dy[M][J] . w[J][K]: A K-contiguous (reduction index j), B row-contiguous; no split
 int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* w, int M, int64_t K,
-                              int J, float* dx, __hip_bfloat16* dx16, int64_t lddx, hipStream_t st) {
+                              int J, float* dx, __hip_bfloat16* dx16, int64_t lddx, bool f16, hipStream_t st) {
     typedef KCLoader256<64> AL;
     typedef MCLoader256 BL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (K + T - 1) / T;
-    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     AL::P ap{dy, lddy, M, 0};
     BL::P bp{w, K, (int)K, J};
     EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0, dx16};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 4>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
-                       (int)tiles_m, (int)tiles_n, 1, J / BKH, J / BKH);
-    GN_LAUNCH_CHECK(name);
-    return 0;
+    return launch_256<AL, BL, 4>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, J / BKH, J / BKH, f16, st);
 }
 
 // dw[J][K] (fp32) = dy[M][J]^T . x[M][K]: both operands row-contiguous (the reduction index m is the slow one), no split:
 // a short reduction (M / 64 K-tiles) into a huge output — the 256^2 tile quarters the operand traffic per output byte
 int launch_linear_dw_bf16_256(const char* name, const __hip_bfloat16* dy, int64_t lddy, const __hip_bfloat16* x, int64_t ldx, int M,
-                              int64_t K, int J, float* dw, hipStream_t st) {
+                              int64_t K, int J, float* dw, bool f16, hipStream_t st) {
     typedef MCLoader256 AL;
     typedef MCLoader256 BL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
     const int64_t tiles_m = (J + T - 1) / T, tiles_n = (K + T - 1) / T;
-    GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     const int ktiles = (M + BKH - 1) / BKH;
     AL::P ap{dy, lddy, J, M};
     BL::P bp{x, ldx, (int)K, M};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 5>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), LDS_BYTES, st, ap, bp, ep,
-                       (int)tiles_m, (int)tiles_n, 1, ktiles, ktiles);
-    GN_LAUNCH_CHECK(name);
-    return 0;
+    return launch_256<AL, BL, 5>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, f16, st);
 }
 
 // conv 3x3 weight gradient on the zero-padded pixel grid: slabs[split][Cout][9*Cin] (fp32), reduced by the caller
 int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const __hip_bfloat16* dy_pad, int Wp2, int Cin, int Cout,
-                          int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
+                          int64_t Mp, float* slabs, int nsplit, bool f16, hipStream_t st) {
     typedef MCLoader256 AL;
     typedef ConvWgradBLoader256 BL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<AL, BL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { set_error("%s: cannot reserve %d bytes of LDS: %s", name, LDS_BYTES, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
     const int64_t tiles_m = (Cout + T - 1) / T, tiles_n = (9 * Cin + T - 1) / T;
     const int ktiles = (int)((Mp + BKH - 1) / BKH);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
@@ -630,11 +605,7 @@ int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const _
     AL::P ap{dy_pad, Cout, Cout, Mp};
     BL::P bp{x_pad, Wp2, Cin, Mp};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
-    GN_REQUIRE(tiles_m * tiles_n * nsplit < (1ll << 31), GOALNET_E_SHAPE, "%s: too many blocks", name);
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, 2>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
-                       ap, bp, ep, (int)tiles_m, (int)tiles_n, 1, ktiles, kps);
-    GN_LAUNCH_CHECK(name);
-    return 0;
+    return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, f16, st);
 }
 
 }  // namespace goalnet

@@ -629,7 +629,19 @@ static int wgrad_splits(int64_t M, int Cin, int Cout) {
     const int64_t smax = ktiles / 4 > 1 ? ktiles / 4 : 1;      // >= 4 K-tiles per split (small sub-batches: few pixels)
     if (s > smax) s = smax;
     if (s > 512) s = 512;
-    if (s >= 8) s = (s + 7) / 8 * 8 <= smax ? (s + 7) / 8 * 8 : s / 8 * 8;      // whole XCD groups (launch_gemm's XCD-local order)
+    if (s >= 8) {
+        // whole XCD groups (launch_gemm's XCD-local order), and among the multiples of 8 between s and 2 s the one whose
+        // tiles x splits fills the chip's 512 resident blocks (256 CUs x 2) in whole rounds: conv3's 72 tiles x 32 splits were
+        // 4.5 rounds, i.e. a last round with half the chip idle (measured: MFMA busy 67 %); 72 x 64 are 9 full ones
+        int64_t best = (s + 7) / 8 * 8 <= smax ? (s + 7) / 8 * 8 : s / 8 * 8;
+        double best_eff = 0.0;
+        for (int64_t c = best; c <= 2 * s + 8 && c <= smax && c <= 1024; c += 8) {
+            const int64_t blocks = tiles * c, rounds = (blocks + 511) / 512;
+            const double eff = (double)blocks / (double)(rounds * 512);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+        }
+        s = best;
+    }
     const int kps = (int)((ktiles + s - 1) / s);
     return (ktiles + kps - 1) / kps;
 }

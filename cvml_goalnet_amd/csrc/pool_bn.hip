@@ -163,13 +163,22 @@ __device__ __forceinline__ float4 load_dz4(const __hip_bfloat16* q) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 
+// IEEE fp16 tensors (precision = "fp16"): same 8 bytes per 4 values as bf16, another conversion
+struct h16raw { uint2 u; };
+__device__ __forceinline__ float h16_lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+__device__ __forceinline__ float4 f4_of_h16(const uint2& u) { return make_float4(h16_lo(u.x), h16_hi(u.x), h16_lo(u.y), h16_hi(u.y)); }
+__device__ __forceinline__ float4 load_dz4(const _Float16* q) { return f4_of_h16(*reinterpret_cast<const uint2*>(q)); }
+
 // the same in two steps for software-pipelined loops: the raw load is issued early, the conversion waits for it later
 __device__ __forceinline__ float4 load_dz4_raw(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ uint2 load_dz4_raw(const __hip_bfloat16* q) { return *reinterpret_cast<const uint2*>(q); }
+__device__ __forceinline__ h16raw load_dz4_raw(const _Float16* q) { return h16raw{*reinterpret_cast<const uint2*>(q)}; }
 __device__ __forceinline__ float4 dz4_of(const float4& v) { return v; }
 __device__ __forceinline__ float4 dz4_of(const uint2& u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
+__device__ __forceinline__ float4 dz4_of(const h16raw& r) { return f4_of_h16(r.u); }
 
 // ---- backward phase 1: partial sums of dz and dz * xhat
 template <typename DZ, typename PT>
@@ -302,6 +311,20 @@ __device__ __forceinline__ float4 store_p4(__hip_bfloat16* q, const float4& v) {
     *reinterpret_cast<uint2*>(q) = u;
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
+template <bool F16>
+__device__ __forceinline__ unsigned pack_h16x2(float a, float b) {
+    if (F16) {
+        const _Float16 x = (_Float16)a, y = (_Float16)b;
+        return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    }
+    return pack_bf16x2(a, b);
+}
+__device__ __forceinline__ float4 store_p4(_Float16* q, const float4& v) {
+    const uint2 u = make_uint2(pack_h16x2<true>(v.x, v.y), pack_h16x2<true>(v.z, v.w));
+    *reinterpret_cast<uint2*>(q) = u;
+    return f4_of_h16(u);
+}
+__device__ __forceinline__ float4 load_p4(const _Float16* q) { return f4_of_h16(*reinterpret_cast<const uint2*>(q)); }
 __device__ __forceinline__ float4 load_p4(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ float4 load_p4(const __hip_bfloat16* q) {
     const uint2 u = *reinterpret_cast<const uint2*>(q);
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const YT* __re
 }
 
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
-template <typename DZ, typename PT, int NP>
+template <typename DZ, typename PT, int NP, bool F16>
 __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const uint8_t* __restrict__ idx,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
                 if (dyn) *reinterpret_cast<float4*>(dyn + o) = a4;
                 if (dpn)
                     *reinterpret_cast<uint2*>(dpn + ((int64_t)(h + 1) * (Wc + 2) + w + 1) * C) =
-                        make_uint2(pack_bf16x2(a4.x, a4.y), pack_bf16x2(a4.z, a4.w));
+                        make_uint2(pack_h16x2<F16>(a4.x, a4.y), pack_h16x2<F16>(a4.z, a4.w));
                 acc[0][0] += (double)a4.x; acc[0][1] += (double)a4.y; acc[0][2] += (double)a4.z; acc[0][3] += (double)a4.w;
             }
             __syncthreads();
@@ -531,17 +554,17 @@ static void launch_pool_fwd_v2(int nparts, size_t lds, hipStream_t st, const YT*
     }
 }
 
-template <typename DZ, typename PT>
+template <typename DZ, typename PT, bool F16 = false>
 static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const PT* p, const uint8_t* idx, const float* coef3,
                                  float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
     const dim3 grid(nparts * (C / CS)), block(256);
     const int bands = row_bands(nparts, N, Hc);
     switch ((Wc - 2 + 31) / 32) {                               // passes of 32 pixels per pooled row; the LDS limit keeps Wp <= 136
-    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 1>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 2>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 3>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 4>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 5>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 1, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 2, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 3, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 4, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 5, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
     }
 }
 
@@ -577,7 +600,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
 /* p stored as bf16; y fp32 (y_bf16 = 0) or bf16 as goalnet_conv3x3_fwd_bf16p_o16 writes it (rounding is monotonic: the
  * maximum of the rounded values is the rounded maximum, so p is the same either way; only ties in the argmax differ) */
 int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_t* idx, double* partials, int nparts,
-                                 int N, int Hc, int Wc, int C, void* stream) {
+                                 int N, int Hc, int Wc, int C, int f16, void* stream) {
     GN_REQUIRE(y && p_bf16 && partials, GOALNET_E_NULL, "pool_bnstats_fwd_p16: null pointer");
     GN_PARTS_OK("pool_bnstats_fwd_p16");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: need Hc, Wc >= 3");
@@ -588,7 +611,11 @@ int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "pool_bnstats_fwd_p16: image too wide for the rolling LDS rows");
     const size_t need = lds < 16384 ? 16384 : lds;
     typedef __hip_bfloat16 bf;
-    if (y_bf16) launch_pool_fwd_v2<bf, bf>(nparts, need, (hipStream_t)stream, (const bf*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);
+    typedef _Float16 hf;
+    if (f16) {
+        if (y_bf16) launch_pool_fwd_v2<hf, hf>(nparts, need, (hipStream_t)stream, (const hf*)y, (hf*)p_bf16, idx, partials, N, Hc, Wc, C);
+        else launch_pool_fwd_v2<float, hf>(nparts, need, (hipStream_t)stream, (const float*)y, (hf*)p_bf16, idx, partials, N, Hc, Wc, C);
+    } else if (y_bf16) launch_pool_fwd_v2<bf, bf>(nparts, need, (hipStream_t)stream, (const bf*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);
     else launch_pool_fwd_v2<float, bf>(nparts, need, (hipStream_t)stream, (const float*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("pool_bnstats_fwd_p16");
     return 0;
@@ -620,7 +647,7 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
 
 /* dz and p each fp32 (flag 0) or bf16 (flag 1) */
 int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const float* mean, const float* invstd,
-                            double* partials, int nparts, int64_t npix, int C, void* stream) {
+                            double* partials, int nparts, int64_t npix, int C, int f16, void* stream) {
     GN_REQUIRE(dz && p && mean && invstd && partials, GOALNET_E_NULL, "bn_bwd_reduce_t: null pointer");
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_t: bad dims");
     GN_PARTS_OK("bn_bwd_reduce_t");
@@ -628,7 +655,11 @@ int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf
     const dim3 grid(nparts), block(256);
     hipStream_t st = (hipStream_t)stream;
     typedef __hip_bfloat16 bf;
-    if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C);
+    typedef _Float16 hf;
+    if (f16 && dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, hf>), grid, block, 0, st, (const hf*)dz, (const hf*)p, mean, invstd, partials, npix, C);
+    else if (f16 && dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, float>), grid, block, 0, st, (const hf*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    else if (f16 && p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, hf>), grid, block, 0, st, (const float*)dz, (const hf*)p, mean, invstd, partials, npix, C);
+    else if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C);
     else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C);
     else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C);
     else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C);
@@ -668,7 +699,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
 
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                             void* stream) {
+                             int f16, void* stream) {
     GN_REQUIRE(dz && p && idx && coef3 && dy_pad_bf16 && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p: null pointer");
     GN_PARTS_OK("bnpool_bwd_bf16p");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: bad dims (C %% 32)");
@@ -677,7 +708,8 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
     const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
-    launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+    if (f16) launch_bnpool_bwd_v2<float, float, true>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
+    else launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p");
     return 0;
 }
@@ -685,7 +717,7 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
 /* dz and p each fp32 (flag 0) or bf16 (flag 1) */
 int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
                                float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                               void* stream) {
+                               int f16, void* stream) {
     GN_REQUIRE(dz && p && idx && coef3 && (dy || dy_pad_bf16) && dbias_partials, GOALNET_E_NULL, "bnpool_bwd_bf16p_t: null pointer");
     GN_PARTS_OK("bnpool_bwd_bf16p_t");
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: bad dims (C %% 32)");
@@ -697,7 +729,12 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
     hipStream_t st = (hipStream_t)stream;
     typedef __hip_bfloat16 bf;
     bf* dp = (bf*)dy_pad_bf16;
-    if (dz_bf16 && p_bf16) launch_bnpool_bwd_v2<bf, bf>(nparts, need, st, (const bf*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    typedef _Float16 hf;
+    if (f16 && dz_bf16 && p_bf16) launch_bnpool_bwd_v2<hf, hf, true>(nparts, need, st, (const hf*)dz, (const hf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (f16 && dz_bf16)      launch_bnpool_bwd_v2<hf, float, true>(nparts, need, st, (const hf*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (f16 && p_bf16)       launch_bnpool_bwd_v2<float, hf, true>(nparts, need, st, (const float*)dz, (const hf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (f16)                 launch_bnpool_bwd_v2<float, float, true>(nparts, need, st, (const float*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
+    else if (dz_bf16 && p_bf16) launch_bnpool_bwd_v2<bf, bf>(nparts, need, st, (const bf*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
     else if (dz_bf16)      launch_bnpool_bwd_v2<bf, float>(nparts, need, st, (const bf*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
     else if (p_bf16)       launch_bnpool_bwd_v2<float, bf>(nparts, need, st, (const float*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
     else                   launch_bnpool_bwd_v2<float, float>(nparts, need, st, (const float*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);

@@ -344,8 +344,12 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t n, double lr, double beta1, double beta2,
                                                   float eps, const int64_t* __restrict__ step_dev, int64_t step_host, float gs,
-                                                  uint2* __restrict__ shadow, int64_t sh_b4, int64_t sh_e4) {
-    const double t = (double)(step_dev ? *step_dev + step_host : step_host);       // device counter + bias, or the host count
+                                                  uint2* __restrict__ shadow, int64_t sh_b4, int64_t sh_e4, int sh_f16,
+                                                  const int64_t* __restrict__ bad_step) {
+    const int64_t ti = step_dev ? *step_dev + step_host : step_host;               // device counter + bias, or the host count
+    // precision = "fp16": goalnet_grad_finite_check stamped this step as overflowed -> the whole update is skipped
+    if (bad_step && *bad_step == ti) return;
+    const double t = (double)ti;
     const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
     const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
@@ -362,15 +366,43 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
-        if (shadow && i >= sh_b4 && i < sh_e4) {       // bf16 copy of the updated parameters of one slice (the next step's GEMM operand)
-            const __hip_bfloat16 a = __float2bfloat16(pp.x), b = __float2bfloat16(pp.y), c = __float2bfloat16(pp.z), d = __float2bfloat16(pp.w);
-            shadow[i - sh_b4] = make_uint2((unsigned)*reinterpret_cast<const unsigned short*>(&a) | ((unsigned)*reinterpret_cast<const unsigned short*>(&b) << 16),
-                                           (unsigned)*reinterpret_cast<const unsigned short*>(&c) | ((unsigned)*reinterpret_cast<const unsigned short*>(&d) << 16));
+        if (shadow && i >= sh_b4 && i < sh_e4) {       // 16-bit copy of the updated parameters of one slice (the next step's GEMM operand)
+            if (sh_f16) {
+                const _Float16 a = (_Float16)pp.x, b = (_Float16)pp.y, c = (_Float16)pp.z, d = (_Float16)pp.w;
+                shadow[i - sh_b4] = make_uint2((unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16),
+                                               (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16));
+            } else {
+                const __hip_bfloat16 a = __float2bfloat16(pp.x), b = __float2bfloat16(pp.y), c = __float2bfloat16(pp.z), d = __float2bfloat16(pp.w);
+                shadow[i - sh_b4] = make_uint2((unsigned)*reinterpret_cast<const unsigned short*>(&a) | ((unsigned)*reinterpret_cast<const unsigned short*>(&b) << 16),
+                                               (unsigned)*reinterpret_cast<const unsigned short*>(&c) | ((unsigned)*reinterpret_cast<const unsigned short*>(&d) << 16));
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
         adam1(p[i], g[i], m[i], v[i], b2, omb1, omb2, eps, step_size, bc2_sqrt, gs);
+    }
+}
+
+// x *= s (the loss scale of precision = "fp16" on dL/dpred)
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64_t n, float s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+// any non-finite value in g -> *bad_step = max(*bad_step, this step's 1-based count): the fused Adam of this step then returns
+// without touching anything (adam_kernel) and bumps nothing; no reset between steps is needed, any number of blocks may write
+__global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, int64_t n, const int64_t* __restrict__ step,
+                                                               int64_t step_bias, int64_t* __restrict__ bad_step,
+                                                               int64_t* __restrict__ skipped) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.0e38f);                 // inf or nan
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) {
+        const unsigned long long t = (unsigned long long)(*step + step_bias);
+        const unsigned long long old = atomicMax(reinterpret_cast<unsigned long long*>(bad_step), t);
+        if (old != t && skipped) atomicAdd(reinterpret_cast<unsigned long long*>(skipped), 1ull);       // first reporter of this step
     }
 }
 
@@ -491,25 +523,57 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 
 static int adam_launch(const char* who, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                        double beta2, double eps, const int64_t* step_dev, int64_t step_host, float grad_scale, void* stream,
-                       void* shadow = nullptr, int64_t sh_begin = 0, int64_t sh_count = 0) {
+                       void* shadow = nullptr, int64_t sh_begin = 0, int64_t sh_count = 0, int sh_f16 = 0, const int64_t* bad_step = nullptr) {
     GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "%s: null pointer", who);
     GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "%s: bad count", who);
     GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "%s: arenas must be 16-byte aligned", who);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
-                       (float)eps, step_dev, step_host, grad_scale, (uint2*)shadow, sh_begin >> 2, (sh_begin + sh_count) >> 2);
+                       (float)eps, step_dev, step_host, grad_scale, (uint2*)shadow, sh_begin >> 2, (sh_begin + sh_count) >> 2, sh_f16, bad_step);
     GN_LAUNCH_CHECK(who);
     return 0;
 }
 
 int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                                  double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* shadow_bf16,
-                                 int64_t shadow_begin, int64_t shadow_count, void* stream) {
+                                 int64_t shadow_begin, int64_t shadow_count, int f16, void* stream) {
     GN_REQUIRE(step && shadow_bf16, GOALNET_E_NULL, "adam_step_dev_shadow: null pointer");
     GN_REQUIRE(shadow_begin >= 0 && shadow_count > 0 && shadow_begin + shadow_count <= n && (shadow_begin & 3) == 0 && (shadow_count & 3) == 0,
                GOALNET_E_SHAPE, "adam_step_dev_shadow: the shadowed slice must lie inside the arena, offset and length multiples of 4");
     GN_REQUIRE((reinterpret_cast<uintptr_t>(shadow_bf16) & 7u) == 0, GOALNET_E_ALIGN, "adam_step_dev_shadow: shadow must be 8-byte aligned");
     return adam_launch("adam_step_dev_shadow", p, g, m, v, n, lr, beta1, beta2, eps, step, step_bias, grad_scale, stream, shadow_bf16,
-                       shadow_begin, shadow_count);
+                       shadow_begin, shadow_count, f16);
+}
+
+/* precision = "fp16" (loss-scaled gradients): the same two entry points with an overflow guard — the update is skipped when
+ * goalnet_grad_finite_check stamped this step (*bad_step == *step + step_bias). shadow may be NULL. */
+int goalnet_adam_step_dev_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                  double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* shadow_16,
+                                  int64_t shadow_begin, int64_t shadow_count, int f16, const int64_t* bad_step, void* stream) {
+    GN_REQUIRE(step && bad_step, GOALNET_E_NULL, "adam_step_dev_guarded: null pointer");
+    if (shadow_16) {
+        GN_REQUIRE(shadow_begin >= 0 && shadow_count > 0 && shadow_begin + shadow_count <= n && (shadow_begin & 3) == 0 && (shadow_count & 3) == 0,
+                   GOALNET_E_SHAPE, "adam_step_dev_guarded: the shadowed slice must lie inside the arena, offset and length multiples of 4");
+        GN_REQUIRE((reinterpret_cast<uintptr_t>(shadow_16) & 7u) == 0, GOALNET_E_ALIGN, "adam_step_dev_guarded: shadow must be 8-byte aligned");
+    }
+    return adam_launch("adam_step_dev_guarded", p, g, m, v, n, lr, beta1, beta2, eps, step, step_bias, grad_scale, stream, shadow_16,
+                       shadow_begin, shadow_16 ? shadow_count : 0, f16, bad_step);
+}
+
+int goalnet_scale(float* x, int64_t n, float s, void* stream) {
+    GN_REQUIRE(x, GOALNET_E_NULL, "scale: null pointer");
+    GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "scale: bad count");
+    hipLaunchKernelGGL(scale_kernel, dim3(grid1d(n, 8192)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    GN_LAUNCH_CHECK("scale");
+    return 0;
+}
+
+int goalnet_grad_finite_check(const float* g, int64_t n, const int64_t* step, int64_t step_bias, int64_t* bad_step, int64_t* skipped,
+                              void* stream) {
+    GN_REQUIRE(g && step && bad_step, GOALNET_E_NULL, "grad_finite_check: null pointer");
+    GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "grad_finite_check: bad count");
+    hipLaunchKernelGGL(grad_finite_check_kernel, dim3(grid1d(n, 1024)), dim3(256), 0, (hipStream_t)stream, g, n, step, step_bias, bad_step, skipped);
+    GN_LAUNCH_CHECK("grad_finite_check");
+    return 0;
 }
 
 int goalnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,

@@ -30,7 +30,7 @@ def _chk(*ts):
             continue
         if not t.is_cuda:
             raise _lib.GoalnetError("expected a GPU tensor")
-        if t.dtype not in (F32, torch.float64, torch.uint8, torch.bfloat16):
+        if t.dtype not in (F32, torch.float64, torch.uint8, torch.bfloat16, torch.float16):
             raise _lib.GoalnetError(f"unexpected dtype {t.dtype}")
 
 
@@ -116,9 +116,9 @@ def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     _chk(y, p, idx, partials)
     assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
     assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
-    if p.dtype == torch.bfloat16:                   # pooled activation stored as bf16 (statistics of the stored values)
-        check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), int(y.dtype == torch.bfloat16), p.data_ptr(), _p(idx), partials.data_ptr(),
-                                                 _rows(partials, 2 * C), N, Hc, Wc, C, _s()), "pool_bnstats_fwd_p16")
+    if p.dtype in H16:                              # pooled activation stored in 16 bits (statistics of the stored values)
+        check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), int(y.dtype in H16), p.data_ptr(), _p(idx), partials.data_ptr(),
+                                                 _rows(partials, 2 * C), N, Hc, Wc, C, _f16(y, p), _s()), "pool_bnstats_fwd_p16")
         return
     assert y.dtype == F32
     check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
@@ -138,10 +138,10 @@ def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
     """dz: fp32, or bf16 as the *_o16 GEMMs write it; p: fp32, or bf16 as pool_bnstats_fwd stores it into a bf16 tensor"""
     _chk(dz, p, mean, invstd, partials)
     assert dz.numel() == p.numel() == npix * C
-    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
-        check(lib().goalnet_bn_bwd_reduce_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
-                                            mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), _rows(partials, 2 * C), npix, C, _s()),
-              "bn_bwd_reduce_t")
+    if dz.dtype in H16 or p.dtype in H16:
+        check(lib().goalnet_bn_bwd_reduce_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
+                                            mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), _rows(partials, 2 * C), npix, C,
+                                            _f16(dz, p), _s()), "bn_bwd_reduce_t")
         return
     check(lib().goalnet_bn_bwd_reduce(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
                                       _rows(partials, 2 * C), npix, C, _s()), "bn_bwd_reduce")
@@ -158,10 +158,10 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dbias_partials)
     npool = N * (Hc - 2) * (Wc - 2) * C
     assert dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C
-    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
-        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
+    if dz.dtype in H16 or p.dtype in H16:
+        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
                                                idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), None, dbias_partials.data_ptr(),
-                                               _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p_t")
+                                               _rows(dbias_partials, C), N, Hc, Wc, C, _f16(dz, p), _s()), "bnpool_bwd_bf16p_t")
         return
     check(lib().goalnet_bnpool_bwd(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(),
                                    dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd")
@@ -169,15 +169,15 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
 
 def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dypad, dbias_partials)
-    assert dypad.dtype == torch.bfloat16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
-    if dz.dtype == torch.bfloat16 or p.dtype == torch.bfloat16:
-        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype == torch.bfloat16), p.data_ptr(), int(p.dtype == torch.bfloat16),
+    assert dypad.dtype in H16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
+    if dz.dtype in H16 or p.dtype in H16:
+        check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
                                                idx.data_ptr(), coef3.data_ptr(), _p(dy), dypad.data_ptr(), dbias_partials.data_ptr(),
-                                               _rows(dbias_partials, C), N, Hc, Wc, C, _s()), "bnpool_bwd_bf16p_t")
+                                               _rows(dbias_partials, C), N, Hc, Wc, C, _f16(dz, p, dypad), _s()), "bnpool_bwd_bf16p_t")
         return
     check(lib().goalnet_bnpool_bwd_bf16p(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), _p(dy),
-                                         dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C, _s()),
-          "bnpool_bwd_bf16p")
+                                         dypad.data_ptr(), dbias_partials.data_ptr(), _rows(dbias_partials, C), N, Hc, Wc, C,
+                                         _f16(dypad), _s()), "bnpool_bwd_bf16p")
 
 
 def partials_sum(partials, nparts, stride, C, out):
@@ -216,68 +216,77 @@ def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
 
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+H16 = (BF16, F16)          # the 16-bit storage formats of the reduced-precision engine; the C ABI's `f16` flag = (dtype == float16)
+
+
+def _f16(*ts):
+    """the `f16` flag of a call: 1 when its 16-bit tensors are torch.float16, 0 for bfloat16 (they must agree)"""
+    kinds = {t.dtype for t in ts if t is not None and t.dtype in H16}
+    assert len(kinds) <= 1, "16-bit operands of one call must share a format"
+    return int(F16 in kinds)
 
 
 def cast_bf16(x, y):
     _chk(x, y)
-    assert x.dtype == F32 and y.dtype == BF16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
-    check(lib().goalnet_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _s()), "cast_bf16")
+    assert x.dtype == F32 and y.dtype in H16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().goalnet_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _f16(y), _s()), "cast_bf16")
     return y
 
 
 def cast_f32(x, y):
     _chk(x, y)
-    assert x.dtype == BF16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
-    check(lib().goalnet_cast_f32(x.data_ptr(), y.data_ptr(), x.numel(), _s()), "cast_f32")
+    assert x.dtype in H16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().goalnet_cast_f32(x.data_ptr(), y.data_ptr(), x.numel(), _f16(x), _s()), "cast_f32")
     return y
 
 
 def bn_apply_bf16(x, scale, shift, y, C):
     _chk(x, scale, shift, y)
-    assert x.dtype in (F32, BF16) and y.dtype == BF16 and x.numel() == y.numel() and scale.numel() == C
-    if x.dtype == BF16:
-        check(lib().goalnet_bn_apply_bf16_p16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _s()), "bn_apply_bf16_p16")
+    assert x.dtype in (F32,) + H16 and y.dtype in H16 and x.numel() == y.numel() and scale.numel() == C
+    if x.dtype in H16:
+        check(lib().goalnet_bn_apply_bf16_p16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _f16(x, y), _s()), "bn_apply_bf16_p16")
         return y
-    check(lib().goalnet_bn_apply_bf16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _s()), "bn_apply_bf16")
+    check(lib().goalnet_bn_apply_bf16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _f16(y), _s()), "bn_apply_bf16")
     return y
 
 
 def conv3x3_fwd_bf16(x, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(x, w, bias, y)
-    assert x.dtype == BF16 and w.dtype == BF16 and y.dtype == F32
+    assert x.dtype in H16 and w.dtype == x.dtype and y.dtype == F32
     assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
-    check(lib().goalnet_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
+    check(lib().goalnet_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _f16(x, w), _s()),
           "conv3x3_fwd_bf16")
     return y
 
 
-def padded_bf16_alloc(N, H, W, C, device):
-    """Zeroed bf16 buffer for a padded [N][H+2][W+2][C] tensor with its guard bands; returns (buffer, view at padded pixel 0)."""
+def padded_bf16_alloc(N, H, W, C, device, dtype=torch.bfloat16):
+    """Zeroed 16-bit buffer for a padded [N][H+2][W+2][C] tensor with its guard bands; returns (buffer, view at padded pixel 0)."""
     import ctypes as _ct
     tot, off = _ct.c_int64(), _ct.c_int64()
     check(lib().goalnet_bf16_padded_layout(N, H, W, C, _ct.byref(tot), _ct.byref(off)), "bf16_padded_layout")
-    buf = torch.zeros(tot.value, dtype=BF16, device=device)
+    buf = torch.zeros(tot.value, dtype=dtype, device=device)
     return buf, buf[off.value:]
 
 
 def to_bf16_padded(x, scale, shift, ypad, N, H, W, C):
     _chk(x, scale, shift, ypad)
-    assert x.dtype in (F32, BF16) and ypad.dtype == BF16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
-    if x.dtype == BF16:
-        check(lib().goalnet_to_bf16_padded_p16(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _s()), "to_bf16_padded_p16")
+    assert x.dtype in (F32,) + H16 and ypad.dtype in H16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
+    if x.dtype in H16:
+        check(lib().goalnet_to_bf16_padded_p16(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _f16(x, ypad), _s()), "to_bf16_padded_p16")
         return ypad
-    check(lib().goalnet_to_bf16_padded(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _s()), "to_bf16_padded")
+    check(lib().goalnet_to_bf16_padded(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _f16(ypad), _s()), "to_bf16_padded")
     return ypad
 
 
 def conv3x3_fwd_bf16p(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(xpad, w, bias, y)
-    assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == F32
+    assert xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == F32
     assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
     nbytes = lib().goalnet_conv3x3_fwd_bf16p_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=y.device) if nbytes else None
     check(lib().goalnet_conv3x3_fwd_bf16p(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout,
-                                          _p(ws), nbytes, _s()), "conv3x3_fwd_bf16p")
+                                          _p(ws), nbytes, _f16(xpad, w), _s()), "conv3x3_fwd_bf16p")
     return y
 
 
@@ -288,31 +297,32 @@ def conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout) -> bool:
 def conv3x3_fwd_bf16p_o16(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     """bf16 result (bias None, relu False: the data gradient); only for dims conv3x3_fwd_bf16p_o16_ok accepts"""
     _chk(xpad, w, bias, y)
-    assert xpad.dtype == BF16 and w.dtype == BF16 and y.dtype == BF16
+    assert xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == xpad.dtype
     assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
-    check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()),
+    check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout,
+                                              _f16(xpad, w, y), _s()),
           "conv3x3_fwd_bf16p_o16")
     return y
 
 
 def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
     _chk(xpad, dypad, dw)
-    assert xpad.dtype == BF16 and dypad.dtype == BF16 and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin
+    assert xpad.dtype in H16 and dypad.dtype == xpad.dtype and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin
     nbytes = lib().goalnet_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
     check(lib().goalnet_conv3x3_wgrad_bf16(xpad.data_ptr(), dypad.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-                                           N, H, W, Cin, Cout, _s()), "conv3x3_wgrad_bf16")
+                                           N, H, W, Cin, Cout, _f16(xpad, dypad), _s()), "conv3x3_wgrad_bf16")
     return dw
 
 
 def linear_bwd_dx_bf16(dy, w, dx, mult=None):
     _chk(dy, w, dx, mult)
-    assert dy.dtype == BF16 and w.dtype == BF16 and dx.dtype == F32
+    assert dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32
     M, J = dy.shape
     K = dx.shape[1]
     assert w.numel() == J * K and dx.shape[0] == M
     check(lib().goalnet_linear_bwd_dx_bf16(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
-                                           dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_bf16")
+                                           dx.data_ptr(), _ld(dx), M, K, J, _f16(dy, w), _s()), "linear_bwd_dx_bf16")
     return dx
 
 
@@ -323,27 +333,28 @@ def linear_bwd_dx_bf16_o16_ok(M, K, J) -> bool:
 def linear_bwd_dx_bf16_o16(dy, w, dx):
     """bf16 result; only for dims linear_bwd_dx_bf16_o16_ok accepts"""
     _chk(dy, w, dx)
-    assert dy.dtype == BF16 and w.dtype == BF16 and dx.dtype == BF16
+    assert dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == dy.dtype
     M, J = dy.shape
     K = dx.shape[1]
     assert w.numel() == J * K and dx.shape[0] == M
-    check(lib().goalnet_linear_bwd_dx_bf16_o16(dy.data_ptr(), _ld(dy), w.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_bf16_o16")
+    check(lib().goalnet_linear_bwd_dx_bf16_o16(dy.data_ptr(), _ld(dy), w.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _f16(dy, w, dx), _s()),
+          "linear_bwd_dx_bf16_o16")
     return dx
 
 
 def linear_bwd_dw_bf16(dy, x, dw):
     _chk(dy, x, dw)
-    assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == F32
+    assert dy.dtype in H16 and x.dtype == dy.dtype and dw.dtype == F32
     M, J = dy.shape
     K = x.shape[1]
     assert dw.numel() == J * K and x.shape[0] == M
-    check(lib().goalnet_linear_bwd_dw_bf16(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), dw.data_ptr(), M, K, J, _s()), "linear_bwd_dw_bf16")
+    check(lib().goalnet_linear_bwd_dw_bf16(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), dw.data_ptr(), M, K, J, _f16(dy, x), _s()), "linear_bwd_dw_bf16")
     return dw
 
 
 def linear_fwd_bf16(x, w, bias, y, *, relu=False, dropmask=None, mult_out=None):
     _chk(x, w, bias, y, dropmask, mult_out)
-    assert x.dtype == BF16 and w.dtype == BF16
+    assert x.dtype in H16 and w.dtype == x.dtype
     M, K = x.shape
     J = y.shape[1]
     assert w.numel() == J * K and y.shape[0] == M
@@ -351,7 +362,7 @@ def linear_fwd_bf16(x, w, bias, y, *, relu=False, dropmask=None, mult_out=None):
     ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=x.device) if nbytes else None
     check(lib().goalnet_linear_fwd_bf16(x.data_ptr(), _ld(x), w.data_ptr(), _p(bias), int(relu), _p(dropmask),
                                         0 if dropmask is None else _ld(dropmask), y.data_ptr(), _ld(y), _p(mult_out),
-                                        0 if mult_out is None else _ld(mult_out), M, K, J, _p(ws), nbytes, _s()), "linear_fwd_bf16")
+                                        0 if mult_out is None else _ld(mult_out), M, K, J, _p(ws), nbytes, _f16(x, w), _s()), "linear_fwd_bf16")
     return y
 
 
@@ -546,10 +557,33 @@ def adam_step_dev_shadow(p, g, m, v, lr, beta1, beta2, eps, step, shadow, shadow
     """adam_step_dev that also writes bf16(p_new) of arena[shadow_begin : shadow_begin + shadow.numel()] into `shadow`"""
     _chk(p, g, m, v, shadow)
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype == torch.bfloat16 and shadow.is_contiguous()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype in H16 and shadow.is_contiguous()
     check(lib().goalnet_adam_step_dev_shadow(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
-                                             int(step_bias), grad_scale, shadow.data_ptr(), int(shadow_begin), shadow.numel(), _s()),
+                                             int(step_bias), grad_scale, shadow.data_ptr(), int(shadow_begin), shadow.numel(), _f16(shadow), _s()),
           "adam_step_dev_shadow")
+
+
+def adam_step_dev_guarded(p, g, m, v, lr, beta1, beta2, eps, step, bad_step, shadow=None, shadow_begin=0, grad_scale=1.0, step_bias=0):
+    """precision="fp16": adam_step_dev[_shadow] that leaves everything untouched when grad_finite_check stamped this step"""
+    _chk(p, g, m, v, shadow)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or (shadow.dtype in H16 and shadow.is_contiguous()))
+    check(lib().goalnet_adam_step_dev_guarded(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
+                                              int(step_bias), grad_scale, _p(shadow), int(shadow_begin), 0 if shadow is None else shadow.numel(),
+                                              0 if shadow is None else _f16(shadow), _ctr(bad_step), _s()), "adam_step_dev_guarded")
+
+
+def scale_(x, s):
+    _chk(x)
+    assert x.dtype == F32 and x.is_contiguous()
+    check(lib().goalnet_scale(x.data_ptr(), x.numel(), float(s), _s()), "scale")
+    return x
+
+
+def grad_finite_check(g, step, bad_step, skipped, step_bias=1):
+    _chk(g)
+    assert g.dtype == F32 and g.is_contiguous()
+    check(lib().goalnet_grad_finite_check(g.data_ptr(), g.numel(), _ctr(step), int(step_bias), _ctr(bad_step), _ctr(skipped), _s()), "grad_finite_check")
 
 
 def rows_copy_batch(segments):

@@ -78,7 +78,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
  * read three more times per step and every GEMM behind it consumes bf16. The statistics are those of the values as stored.
  * y: fp32 (y_bf16 = 0) or bf16 (1, from goalnet_conv3x3_fwd_bf16p_o16): rounding is monotonic, so p is the same either way. */
 int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_t* idx, double* partials, int nparts,
-                                 int N, int Hc, int Wc, int C, void* stream);
+                                 int N, int Hc, int Wc, int C, int f16, void* stream);
 /* mean/biased var -> invstd, scale = gamma*invstd, shift = beta - mean*scale; running stats updated
  * with `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
 int goalnet_bn_finalize(const double* partials, int nparts, const float* gamma, const float* beta,
@@ -90,7 +90,7 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
 /* same with dz and p each fp32 (flag 0) or bf16 (flag 1): dz as goalnet_linear_bwd_dx_bf16_o16 / goalnet_conv3x3_fwd_bf16p_o16
  * write it, p as goalnet_pool_bnstats_fwd_p16 stores it */
 int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const float* mean, const float* invstd,
-                            double* partials, int nparts, int64_t npix, int C, void* stream);
+                            double* partials, int nparts, int64_t npix, int C, int f16, void* stream);
 /* phase 2: dgamma, dbeta and the three per-channel coefficients of dp = a*dz + b*p + c. */
 int goalnet_bn_bwd_finalize(const double* partials, int nparts, const float* gamma, const float* mean, const float* invstd,
                             int64_t count, int C, float* dgamma, float* dbeta, float* coef3, void* stream);
@@ -104,11 +104,11 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
  * the fp32 dy is optional (NULL when only the bf16 GEMMs consume it). */
 int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx, const float* coef3,
                              float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                             void* stream);
+                             int f16, void* stream);
 /* same with dz and p each fp32 (flag 0) or bf16 (flag 1); either output may be NULL (not both) */
 int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p_bf16, const uint8_t* idx, const float* coef3,
                                float* dy, void* dy_pad_bf16, double* dbias_partials, int nparts, int N, int Hc, int Wc, int C,
-                               void* stream);
+                               int f16, void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
@@ -131,35 +131,38 @@ size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
                           void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
 
-/* ---- precision = "bf16" mode: the same contractions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
- * accumulate). Operands are bf16 copies produced by the two cast passes below; everything else stays fp32.
- * The reference is fp32 (utils.py:37-47): this mode is an extension with its own tolerance (logits <= 1e-3). ---- */
+/* ---- precision = "bf16" / "fp16" modes: the same contractions on the 16-bit matrix cores (v_mfma_f32_32x32x16_bf16 /
+ * v_mfma_f32_32x32x16_f16, fp32 accumulate). Operands are 16-bit copies produced by the cast passes below; everything
+ * else stays fp32. The reference is fp32 (utils.py:37-47): these modes are extensions with their own tolerance
+ * (logits <= 1e-3). Every entry point that reads or writes 16-bit data takes `f16`: 0 = bfloat16, 1 = IEEE binary16 —
+ * both are 16 bits per element, so layouts, alignment rules and workspace sizes are the same ("bf16" in names and
+ * parameter names below stands for "the 16-bit format selected by f16"). ---- */
 /* y_bf16[i] = bf16(x[i]); n % 8 == 0 */
-int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+int goalnet_cast_bf16(const float* x, void* y_bf16, int64_t n, int f16, void* stream);
 /* y[i] = float(x_bf16[i]) (exact); n % 8 == 0 */
-int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
+int goalnet_cast_f32(const void* x_bf16, float* y, int64_t n, int f16, void* stream);
 /* y_bf16 = bf16(x * scale[c] + shift[c]), c = i mod C: the BatchNorm output utils.py:177/182/187, materialised in bf16 */
-int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);
-int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, void* stream);   /* bf16 input */
+int goalnet_bn_apply_bf16(const float* x, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, int f16, void* stream);
+int goalnet_bn_apply_bf16_p16(const void* x_bf16, const float* scale, const float* shift, void* y_bf16, int64_t n, int C, int f16, void* stream);   /* bf16 input */
 /* y = [relu](conv3x3(x_bf16 NHWC, w_bf16 OHWI) + bias), fp32 out; Cin % 64 == 0. Data gradient with flipped weights. */
 int goalnet_conv3x3_fwd_bf16(const void* x_bf16, const void* w_bf16, const float* bias, int relu, float* y,
-                             int N, int H, int W, int Cin, int Cout, void* stream);
+                             int N, int H, int W, int Cin, int Cout, int f16, void* stream);
 /* goalnet_linear_fwd on bf16 operands (x_bf16 [M][K] with leading dim ldx elements, w_bf16 [J][K]); K % 64 == 0 */
 size_t goalnet_linear_fwd_bf16_ws_bytes(int M, int64_t K, int J);
 int goalnet_linear_fwd_bf16(const void* x_bf16, int64_t ldx, const void* w_bf16, const float* bias, int relu,
                             const float* dropmask, int64_t ldmask, float* y, int64_t ldy, float* mult_out, int64_t ldmult,
-                            int M, int64_t K, int J, void* ws, size_t ws_bytes, void* stream);
+                            int M, int64_t K, int J, void* ws, size_t ws_bytes, int f16, void* stream);
 
 /* zero-padded bf16 activations [N][H+2][W+2][C]: with a zero border the 3x3 taps are constant pixel shifts (no masks),
  * which is what lets the weight gradient run as a plain GEMM over the padded pixel grid. The buffer has W+3 zero
  * guard pixels in front of padded pixel 0 and W+3+64 behind; `*_pad` arguments are the address of padded pixel 0 and
  * the caller zeroes the whole buffer once (only interior pixels are ever written). */
 int goalnet_bf16_padded_layout(int N, int H, int W, int C, int64_t* total_elems, int64_t* offset_elems);
-int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);
-int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, void* stream);   /* bf16 input */
+int goalnet_to_bf16_padded(const float* x, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, int f16, void* stream);
+int goalnet_to_bf16_padded_p16(const void* x_bf16, const float* scale, const float* shift, void* y_pad, int N, int H, int W, int C, int f16, void* stream);   /* bf16 input */
 size_t goalnet_conv3x3_fwd_bf16p_ws_bytes(int N, int H, int W, int Cin, int Cout);   /* split-K slabs, as goalnet_conv3x3_fwd */
 int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+                              int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, int f16, void* stream);
 /* The same convolution with its result stored as bf16 [N][H][W][Cout] (bias, relu as above; both off = the data-gradient use
  * with w = flipped weights). Its consumers are HBM-bound passes only: the max-pool of the forward
  * (goalnet_pool_bnstats_fwd_p16) and the BatchNorm backward (goalnet_bn_bwd_reduce_t, goalnet_bnpool_bwd_bf16p_t).
@@ -167,18 +170,18 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
  * 256 x 256 tile only: goalnet_conv3x3_fwd_bf16p_o16_ok() says whether the dims are; otherwise use the fp32-output form. */
 int goalnet_conv3x3_fwd_bf16p_o16_ok(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const float* bias, int relu, void* y_bf16,
-                                  int N, int H, int W, int Cin, int Cout, void* stream);
+                                  int N, int H, int W, int Cin, int Cout, int f16, void* stream);
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
-                               int N, int H, int W, int Cin, int Cout, void* stream);
+                               int N, int H, int W, int Cin, int Cout, int f16, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
-                               float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
+                               float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream);
 /* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */
 int goalnet_linear_bwd_dx_bf16_o16_ok(int M, int64_t K, int J);
 int goalnet_linear_bwd_dx_bf16_o16(const void* dy_bf16, int64_t lddy, const void* w_bf16, void* dx_bf16, int64_t lddx,
-                                   int M, int64_t K, int J, void* stream);
+                                   int M, int64_t K, int J, int f16, void* stream);
 int goalnet_linear_bwd_dw_bf16(const void* dy_bf16, int64_t lddy, const void* x_bf16, int64_t ldx, float* dw,
-                               int M, int64_t K, int J, void* stream);
+                               int M, int64_t K, int J, int f16, void* stream);
 
 /* ---- Linear layers (linear5, audbl.linear3, fusion.0/3/6/9).  utils.py:168-170, 211, 243-253 ---- */
 /* y[m][j] = act(sum_k xa[m][k] * w[j][k] + bias[j]) * dropmask[m][j]
@@ -288,7 +291,18 @@ int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t 
  * multiples of 4): the next step's bf16 GEMM operand (visbl.linear5.weight) without a separate 7.7 GB cast pass */
 int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                                  double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale,
-                                 void* shadow_bf16, int64_t shadow_begin, int64_t shadow_count, void* stream);
+                                 void* shadow_bf16, int64_t shadow_begin, int64_t shadow_count, int f16, void* stream);
+/* precision = "fp16": gradients are computed from a loss-scaled dL/dpred (goalnet_scale) so that the 16-bit activation
+ * gradients stay inside binary16's range; grad_scale of the Adam entry points carries 1 / loss_scale. Overflow guard:
+ * goalnet_grad_finite_check stamps *bad_step = *step + step_bias when g[0..n) holds an inf / nan (any non-finite value of an
+ * earlier layer's gradient reaches the last-computed conv1 gradients: checking the tail bucket is enough) and counts it in
+ * *skipped; goalnet_adam_step_dev_guarded (goalnet_adam_step_dev[_shadow] + that stamp) then leaves p, m, v untouched. */
+int goalnet_scale(float* x, int64_t n, float s, void* stream);
+int goalnet_grad_finite_check(const float* g, int64_t n, const int64_t* step, int64_t step_bias, int64_t* bad_step, int64_t* skipped,
+                              void* stream);
+int goalnet_adam_step_dev_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                  double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* shadow_16 /* nullable */,
+                                  int64_t shadow_begin, int64_t shadow_count, int f16, const int64_t* bad_step, void* stream);
 /* block[0:nrows] = table[*cursor : *cursor + nrows]  (batch_frames[a:b], main.py:181-184); row_bytes % 4 == 0 */
 int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 /* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */
