@@ -30,7 +30,8 @@ Objects on the JSON line:
   parity        pre-sigmoid logit MAE / max-abs of the HIP forward vs that CPU reference on the same 32 frames (n > 16: the
                 branch the timed step runs), weights and dropout masks: on the random-init weights before the first
                 optimizer step, and again on the weights the W + K steps left.
-  bf16_path     (N = 1, --dtype f32) ms_per_step, clips_per_s, roofline, other_kernels, parity of precision="bf16".
+  bf16_path, fp16_path  (N = 1, --dtype f32) ms_per_step, clips_per_s, roofline, other_kernels, parity of precision="bf16" / "fp16"
+                (the same 16-bit engine with bfloat16 / IEEE binary16 storage; fp16 adds a loss scale and an overflow guard).
   comm          (N > 1) ranks, exchange mode, bytes per bucket, a stand-alone all-reduce of bucket 1 (algorithm bandwidth)
                 and the exposed (non-overlapped) wait per step, max over ranks.
   native_40x40_loop  SURVEY.md §8(d) "report additionally frames/s at the reference-native 40x40": the reference's own
@@ -244,7 +245,7 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
     """The same workload, K and W on the other engine (N = 1 only): its own ms/step, roofline and parity."""
     from cvml_goalnet_amd import AVM, synth
     torch.manual_seed(1234)
-    model = AVM(audio_included=audio, device=dev, seed=seed, precision="bf16" if dtype == "bf16" else "fp32")
+    model = AVM(audio_included=audio, device=dev, seed=seed, precision={"bf16": "bf16", "fp16": "fp16"}.get(dtype, "fp32"))
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if not audio:
         aud = None
@@ -254,12 +255,18 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
         parity.update({"weights": "random init (before the first optimizer step)", "dropout": "masks from seed formula", "bn": "train"})
         torch.cuda.empty_cache()
     dt, events, loss = timed_steps(model, aud, vis, lab, warmup, steps, False, dev)
-    roof, others = roofline_of(events, dtype, n, h, w, clips)
+    roof, others = roofline_of(events, "bf16" if dtype == "fp16" else dtype, n, h, w, clips)
+    if roof is not None and dtype == "fp16":
+        roof["kernel"] = roof["kernel"].replace("gemm_bf16_256_kernel<", "gemm_bf16_256_kernel<(F16 = true) ")
+        roof["traffic"], roof["traffic_source"] = None, "no counter pass for the fp16 instantiation (same loads and stores as bf16)"
     out = {"dtype": dtype, "ms_per_step": 1e3 * dt / steps, "clips_per_s": clips * steps / dt, "steps": steps, "warmup": warmup,
            "final_loss": float(loss.item()), "roofline": roof, "other_kernels": others,
-           "arithmetic": "bf16 MFMA contractions (conv2/conv3 fwd+dgrad+wgrad, linear5), bf16 storage of the activations between them; "
-                         "fp32 accumulation, BatchNorm statistics, block 1, AudBl, fusion MLP, loss, gradients, master weights, Adam"
-                         if dtype == "bf16" else "fp32 MFMA everywhere (the reference's arithmetic)"}
+           "arithmetic": (f"{dtype} MFMA contractions (conv2/conv3 fwd+dgrad+wgrad, linear5), {dtype} storage of the activations between them; "
+                          "fp32 accumulation, BatchNorm statistics, block 1, AudBl, fusion MLP, loss, gradients, master weights, Adam"
+                          + ("; loss scale 2^(10 + ceil(log2 n)) on dL/dpred with an overflow guard in the fused Adam" if dtype == "fp16" else ""))
+                         if dtype != "f32" else "fp32 MFMA everywhere (the reference's arithmetic)"}
+    if dtype == "fp16":
+        out["overflow_skipped_steps"] = int(model._guard[1].item())
     if parity is not None:
         parity[f"after_{warmup + steps}_adam_steps"] = logit_parity(model, h, w, synth.BASE_SEED)
         out["parity"] = parity
@@ -472,14 +479,15 @@ def main():
             del model, aud, vis, lab
             torch.cuda.empty_cache()
             if not args.no_second_path:
-                other = "bf16" if args.dtype == "f32" else "f32"
-                try:
-                    res[("bf16" if other == "bf16" else "fp32") + "_path"] = reduced_precision_path(
-                        dev, other, n, h, w, not args.no_audio, seed, args.steps, args.warmup, args.clips, not args.no_cpu_baseline)
-                except Exception as e:
-                    log(f"{other} path failed: {e!r}")
-                    res[("bf16" if other == "bf16" else "fp32") + "_path"] = None
-                torch.cuda.empty_cache()
+                for other in (("bf16", "fp16") if args.dtype == "f32" else ("f32",)):
+                    key = {"bf16": "bf16_path", "fp16": "fp16_path", "f32": "fp32_path"}[other]
+                    try:
+                        res[key] = reduced_precision_path(dev, other, n, h, w, not args.no_audio, seed, args.steps, args.warmup, args.clips,
+                                                          not args.no_cpu_baseline)
+                    except Exception as e:
+                        log(f"{other} path failed: {e!r}")
+                        res[key] = None
+                    torch.cuda.empty_cache()
             if not args.no_native40:
                 try:
                     res["native_40x40_loop"] = native40_loop(dev)

@@ -61,6 +61,40 @@ def _mk_layer(bias=True, bn_channels=0):
     return h
 
 
+class _Fork:
+    """Fork / join onto a second HIP stream for work that is off the critical path of a SMALL step (the reference's 10-frame
+    sub-batches, main.py:177-196): there a step is ~80 short kernels in one dependency chain, most of them too small to fill
+    256 CUs, and the weight-gradient / bias-gradient / AudBl kernels do not feed that chain. Run on a side stream they execute
+    under it; inside a captured HIP graph the fork and join become graph edges (no runtime cost). Results are unchanged (same
+    kernels, same order within each dependency chain). Tensors the side stream reads are kept alive until the join, so the
+    caching allocator cannot hand their memory to the main stream while the side kernels are still running."""
+
+    def __init__(self, model, enabled):
+        self.enabled = enabled
+        self.keep = []
+        if enabled:
+            if model._side_stream is None:
+                model._side_stream = torch.cuda.Stream(device=model._device)
+            self.side = model._side_stream
+            self.forked = False
+
+    def run(self, fn, *tensors):
+        """fn() on the side stream, after everything enqueued on the current stream so far"""
+        if not self.enabled:
+            return fn()
+        self.keep.extend(t for t in tensors if t is not None)
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.forked = True
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.enabled and self.forked:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.forked = False
+        self.keep.clear()
+
+
 class _Spec:
     __slots__ = ("name", "kind", "shape", "numel", "offset", "fan_in")
 
@@ -97,10 +131,11 @@ class AVM(nn.Module):
         self.precision = precision
         self._half = precision in ("bf16", "fp16")
         self._h16 = torch.float16 if precision == "fp16" else torch.bfloat16
-        # dL/dpred is multiplied by loss_scale before backward, the fused Adam divides it out again (a power of two: exact).
-        # 2^12 puts the 16-bit activation gradients of this model (measured: 1e-9 .. 1e-3 at 1 024 frames, scripts/grad_ranges.py)
-        # inside binary16's normal range [6e-5, 65504] with ~2^7 of headroom at the top
-        self.loss_scale = 4096.0 if precision == "fp16" else 1.0
+        # dL/dpred is multiplied by the loss scale before backward, the fused Adam divides it out again (a power of two: exact).
+        # None (fp16 default) = 2^(10 + ceil(log2 n)) for a step of n frames: dL/dpred is O(1/n) and the 16-bit activation
+        # gradients measured with scripts/grad_ranges.py (medians 6e-10 .. 1e-8, maxima 2e-7 .. 8e-6 at n = 1 024; ~1000 x that at
+        # n = 10) then sit at 6e-4 .. 8 — inside binary16's normal range [6.1e-5, 65504] with four orders of magnitude of headroom
+        self.loss_scale = None if precision == "fp16" else 1.0
         self._guard = None             # fp16: int64[2] device counters — step stamped as overflowed, number of skipped updates
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
@@ -134,7 +169,7 @@ class AVM(nn.Module):
         self._hw3 = self._l2 = None
         self._adam_t = 0
         self._adam_segs = None
-        self._arena_grad_scaled = False    # the gradient arena currently holds loss_scale x gradient (fp16 train_step)
+        self._arena_grad_scale = 1.0       # the gradient arena currently holds this factor x gradient (fp16 train_step)
         self._w5b, self._w5b_version = None, None      # bf16 shadow of visbl.linear5.weight and the version stamps it matches
         self._load_count = 0                           # bumped by load_state_dict (its layout kernels write the arena directly)
         self._state = None             # int64[4] device counters: adam step, dropout draw, frame cursor, sub-batch index
@@ -148,6 +183,9 @@ class AVM(nn.Module):
         self.keep_ctx = False          # tests: keep the last train_step's saved tensors in last_ctx
         self.last_ctx = None
         self.last_used_w5b = False
+        self._side_stream = None
+        self._fork = _Fork(self, False)
+        self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
     # ------------------------------------------------------------------------------------------
@@ -483,6 +521,24 @@ class AVM(nn.Module):
         masks = self._masks(n)
         ctx = {"n": n, "h": h, "w": w, "bins": bins, "visual": visual, "audio": audio} if save else None
 
+        fw = 640 if self.audio_included else 512
+        voff = fw - 512
+        cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
+        mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
+        a1 = a2 = None
+        ffork = _Fork(self, n <= self.overlap_rows and self.kernel_events is None and self.audio_included)
+        if self.audio_included:
+            # ---- AudBl, utils.py:214-227: independent of VisBl until the concatenation -> side stream for small steps (_Fork)
+            a1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
+            a2 = torch.empty(n, 128, l2, dtype=F32, device=dev)
+
+            def audbl_fwd():
+                ops.conv1d_fwd(audio, P("audbl.conv1.weight"), P("audbl.conv1.bias"), a1, True, n, 30, bins, 64)
+                ops.conv1d_fwd(a1, P("audbl.conv2.weight"), P("audbl.conv2.bias"), a2, True, n, 64, l1, 128)
+                ops.linear_fwd(a2.view(n, 128 * l2), P("audbl.linear3.weight"), P("audbl.linear3.bias"), cat[:, :128], relu=True,
+                               mult_out=None if mcat is None else mcat[:, :128])
+            ffork.run(audbl_fwd, audio, cat, mcat, a1, a2)
+
         # ---- VisBl, utils.py:172-195
         y1 = torch.empty(n, h1, w1, 64, dtype=F32, device=dev)
         ops.conv1_fwd(visual, P("visbl.conv1.weight"), P("visbl.conv1.bias"), y1, n, h, w)
@@ -525,10 +581,6 @@ class AVM(nn.Module):
         p3, idx3, st3 = self._bn_block(y3, n, hp2, wp2, 512, 3, save, p16=p16_3)
         del y3
 
-        fw = 640 if self.audio_included else 512
-        voff = fw - 512
-        cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
-        mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         k5 = 512 * hp3 * wp3
         if self.grad_sync is not None:
             # shard_linear5: the all-gather of the updated weights has been running under the convolutions above
@@ -548,15 +600,7 @@ class AVM(nn.Module):
 
         if bf and save:
             ctx.update(xh1=xh1, xh2=xh2, bf5=bf5, padgen=(self._padgen["x1"], self._padgen["x2"]))
-        a1 = a2 = None
-        if self.audio_included:
-            # ---- AudBl, utils.py:214-227
-            a1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
-            ops.conv1d_fwd(audio, P("audbl.conv1.weight"), P("audbl.conv1.bias"), a1, True, n, 30, bins, 64)
-            a2 = torch.empty(n, 128, l2, dtype=F32, device=dev)
-            ops.conv1d_fwd(a1, P("audbl.conv2.weight"), P("audbl.conv2.bias"), a2, True, n, 64, l1, 128)
-            ops.linear_fwd(a2.view(n, 128 * l2), P("audbl.linear3.weight"), P("audbl.linear3.bias"), cat[:, :128], relu=True,
-                           mult_out=None if mcat is None else mcat[:, :128])
+        ffork.join()                                # the audio half of `cat` is in place
 
         # ---- fusion, utils.py:242-258, 269-270
         hs, ms = [cat], [mcat]
@@ -614,7 +658,7 @@ class AVM(nn.Module):
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
             ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
-        ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
+        self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
         return dy
 
     def backward_device(self, ctx, dout, on_bucket=None):
@@ -626,6 +670,13 @@ class AVM(nn.Module):
         (h1, w1), (hp1, wp1), (hp2, wp2), (hp3, wp3) = self._sizes(h, w)
         P, G = self._pflat, self._gflat
         hs, ms = ctx["hs"], ctx["ms"]
+        # small steps: weight / bias gradients and the AudBl branch run on a side stream under the dX chain (_Fork)
+        fork = self._fork = _Fork(self, n <= self.overlap_rows and self.kernel_events is None and dout.is_cuda)
+
+        def bucket_done(k):
+            if on_bucket:
+                fork.join()                     # the bucket's gradients may have been written on the side stream
+                on_bucket(k)
 
         # head + fusion MLP (reverse of utils.py:242-258)
         dz = torch.empty(n, 128, dtype=F32, device=dev)
@@ -636,7 +687,7 @@ class AVM(nn.Module):
             ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
         for key, li in (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
             x_in, m_in = hs[li], ms[li]
-            ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"), db=G(f"fusion.{key}.bias"))
+            fork.run(lambda dz=dz, x_in=x_in, key=key: ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"), db=G(f"fusion.{key}.bias")), dz)
             dprev = torch.empty(n, x_in.shape[1], dtype=F32, device=dev)
             ops.linear_bwd_dx(dz, P(f"fusion.{key}.weight"), dprev, mult=m_in)
             dz = dprev
@@ -645,19 +696,21 @@ class AVM(nn.Module):
 
         if self.audio_included:
             l1, l2, bins = ctx["l1"], ctx["l2"], ctx["bins"]
-            dza = dz[:, :128]
-            a2f = ctx["a2"].view(n, 128 * l2)
-            ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"), db=G("audbl.linear3.bias"))
-            da2 = torch.empty(n, 128 * l2, dtype=F32, device=dev)
-            ops.linear_bwd_dx(dza, P("audbl.linear3.weight"), da2, mult=None)
-            ops.relu_bwd(da2, a2f, da2)
-            da1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
-            ops.conv1d_bwd(ctx["a1"], da2, P("audbl.conv2.weight"), da1, G("audbl.conv2.weight"), G("audbl.conv2.bias"), n, 64, l1, 128)
-            ops.relu_bwd(da1, ctx["a1"], da1)
-            ops.conv1d_bwd(ctx["audio"], da1, P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
-        ops.colsum(dz5, G("visbl.linear5.bias"))
-        if on_bucket:
-            on_bucket(0)
+
+            def audbl_bwd():                       # the whole AudBl backward hangs off dz and feeds nothing but its own gradients
+                dza = dz[:, :128]
+                a2f = ctx["a2"].view(n, 128 * l2)
+                ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"), db=G("audbl.linear3.bias"))
+                da2 = torch.empty(n, 128 * l2, dtype=F32, device=dev)
+                ops.linear_bwd_dx(dza, P("audbl.linear3.weight"), da2, mult=None)
+                ops.relu_bwd(da2, a2f, da2)
+                da1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
+                ops.conv1d_bwd(ctx["a1"], da2, P("audbl.conv2.weight"), da1, G("audbl.conv2.weight"), G("audbl.conv2.bias"), n, 64, l1, 128)
+                ops.relu_bwd(da1, ctx["a1"], da1)
+                ops.conv1d_bwd(ctx["audio"], da1, P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
+            fork.run(audbl_bwd, dz)
+        fork.run(lambda: ops.colsum(dz5, G("visbl.linear5.bias")), dz)
+        bucket_done(0)
 
         # linear5 (utils.py:191): dW straight into the arena, dX = grad wrt bnorm3's output
         k5 = 512 * hp3 * wp3
@@ -675,17 +728,15 @@ class AVM(nn.Module):
                                "backward ran; call backward after each forward (as the reference's loop does)")
         if bf and ctx["bf5"]:
             dz5b = ops.cast_bf16(dz5.contiguous(), torch.empty(n, 512, dtype=self._h16, device=dev))
-            ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight"))
-            if on_bucket:
-                on_bucket(1)
+            fork.run(lambda: ops.linear_bwd_dw_bf16(dz5b, ctx["xh3"].view(n, k5), G("visbl.linear5.weight")), dz5b)
+            bucket_done(1)
             if o16_3:
                 ops.linear_bwd_dx_bf16_o16(dz5b, ctx["w5b"], dbn3.view(n, k5))
             else:
                 ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
         else:
-            ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512)
-            if on_bucket:
-                on_bucket(1)
+            fork.run(lambda: ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512), dz)
+            bucket_done(1)
             ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
 
         # block 3 (utils.py:184-187)
@@ -694,11 +745,11 @@ class AVM(nn.Module):
         st2 = ctx["st2"]
         if bf:
             dyp3 = dy3
-            self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
-                        ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
+                                         ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
         else:
-            self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
-                        ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512)
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
+                                         ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
         wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         o16_2 = dz16 and self._bwd16_ok(wp1) and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
@@ -722,11 +773,11 @@ class AVM(nn.Module):
         st1 = ctx["st1"]
         if bf:
             dyp2 = dy2
-            self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
-                        ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
+                                         ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
         else:
-            self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
-                        ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256)
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
+                                         ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
         wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
         ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
@@ -742,6 +793,8 @@ class AVM(nn.Module):
         # block 1 (utils.py:174-177); conv1's input needs no gradient
         dy1 = self._block_bwd(dbn1, ctx, 1, n, h1, w1, 64)
         ops.conv1_wgrad(ctx["visual"], dy1, G("visbl.conv1.weight"), G("visbl.conv1.bias"), n, h, w)
+        fork.join()                                 # every gradient is in the arena before anything downstream (Adam, all-reduce) reads it
+        self._fork = _Fork(self, False)
         if on_bucket:
             on_bucket(2)
 
@@ -807,9 +860,10 @@ class AVM(nn.Module):
             ops.mse_bcast(out, labels, loss, dout)
         sync = self.grad_sync
         self.last_ctx = ctx if self.keep_ctx else None
-        self._arena_grad_scaled = self.loss_scale != 1.0
-        if self.loss_scale != 1.0:
-            ops.scale_(dout.view(-1), self.loss_scale)      # fp16: every activation gradient downstream carries this factor
+        lscale = self._loss_scale_for(n)
+        self._arena_grad_scale = lscale
+        if lscale != 1.0:
+            ops.scale_(dout.view(-1), lscale)               # fp16: every activation gradient downstream carries this factor
         self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)
         scale = 1.0
         if sync is not None:
@@ -822,7 +876,7 @@ class AVM(nn.Module):
             after = min(s.offset for s in self._specs if s.offset > s5.offset)
             ops.grad_finite_check(self._garena[after:], self._state[0], self._guard[0], self._guard[1])
             guard = self._guard[0]
-        self.adam_step(lr, betas, eps, scale / self.loss_scale, _tick=False, _guard=guard)
+        self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard)
         ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
@@ -836,6 +890,11 @@ class AVM(nn.Module):
         after = min(s.offset for s in self._specs if s.offset > s5.offset)
         slo, shi = sync.shard_range(self)
         return [(0, s5.offset), (slo, shi), (after, self._arena_numel)]
+
+    def _loss_scale_for(self, n: int) -> float:
+        if self.loss_scale is not None:
+            return float(self.loss_scale)
+        return float(2 ** (10 + max(0, math.ceil(math.log2(max(n, 1))))))
 
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True, _guard=None):
         """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
@@ -885,7 +944,7 @@ class AVM(nn.Module):
         v = self._view(self._garena, s)
         v = v.reshape(s.shape[0], -1) if s.kind == "lin5" else v
         # fp16: train_step leaves loss_scale x gradient in the arena (the fused Adam divides it out); the drop-in path unscales
-        return v / self.loss_scale if (self.loss_scale != 1.0 and self._arena_grad_scaled) else v
+        return v / self._arena_grad_scale if self._arena_grad_scale != 1.0 else v
 
     def param_of(self, name) -> torch.Tensor:
         s = self.spec(name)
@@ -913,12 +972,13 @@ class _AVMFunction(torch.autograd.Function):
                     prm.grad.untyped_storage().data_ptr() == model._garena.untyped_storage().data_ptr():
                 prm.grad = prm.grad.clone()
         dout = gout.detach().to(device=model._device, dtype=F32).contiguous().view(-1)
-        if model.loss_scale != 1.0:                       # fp16: scaled through the 16-bit chain, unscaled before torch sees .grad
-            dout = ops.scale_(dout.clone(), model.loss_scale)
+        lscale = model._loss_scale_for(saved["n"])
+        if lscale != 1.0:                                 # fp16: scaled through the 16-bit chain, unscaled before torch sees .grad
+            dout = ops.scale_(dout.clone(), lscale)
         model.backward_device(saved, dout)
-        if model.loss_scale != 1.0:
-            ops.scale_(model._garena, 1.0 / model.loss_scale)
-        model._arena_grad_scaled = False
+        if lscale != 1.0:
+            ops.scale_(model._garena, 1.0 / lscale)
+        model._arena_grad_scale = 1.0
         ctx.saved = None
         grads = [model._view(model._garena, s) for s in model._specs]
         return (None, None, None, None, *grads)

@@ -195,7 +195,7 @@ def test_fp16_train_step_vs_oracle(n, h):
         l2 = ((mine - og).norm() / og.norm().clamp_min(1e-30)).item()
         worst = max(worst, l2)
         assert l2 <= 0.05, f"{k}: relative L2 error {l2:.3f}"
-    print(f"[parity] fp16 mode {n}x{h}x{h}: worst weight-gradient relative L2 error {worst:.2e} (loss scale {model.loss_scale:g})")
+    print(f"[parity] fp16 mode {n}x{h}x{h}: worst weight-gradient relative L2 error {worst:.2e} (loss scale {model._arena_grad_scale:g})")
 
 
 def test_fp16_overflow_guard_skips_the_update_and_counts_it():
@@ -212,7 +212,7 @@ def test_fp16_overflow_guard_skips_the_update_and_counts_it():
     torch.cuda.synchronize()
     assert model._guard[1].item() == 1 and model._guard[0].item() == 2    # step 2 stamped, one update skipped
     assert torch.equal(model._arena, good) and torch.equal(model._adam_m, m1), "a skipped step must leave parameters and moments untouched"
-    model.loss_scale = 4096.0
+    model.loss_scale = None                                               # back to the automatic scale
     model.train_step(aud, vis, lab)
     torch.cuda.synchronize()
     assert model._guard[1].item() == 1 and not torch.equal(model._arena, good) and torch.isfinite(model._arena).all()

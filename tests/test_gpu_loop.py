@@ -157,6 +157,29 @@ def test_bf16_graph_loop_survives_writers_outside_the_graph():
         assert torch.equal(sd_e[k], sd_g[k]), k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_side_stream_overlap_changes_nothing_but_the_schedule(precision):
+    """Small steps fork their weight-gradient / bias-gradient / AudBl kernels onto a second HIP stream (avm._Fork). Same kernels,
+    same order inside every dependency chain: eager and graph-driven results must equal the single-stream run bit for bit."""
+    h, sb = 40, 10
+    aud, vis, lab = _video(47, h, True, 21)
+    ref, forked = load_model(h, True, precision), load_model(h, True, precision)
+    ref.overlap_rows = 0                                                  # everything on the current stream
+    e_loss, e_pred = [], []
+    for a in range(0, 47, sb):
+        loss, pred = ref.train_step(aud[a:a + sb].to(DEV), vis[a:a + sb].to(DEV), lab[a:a + sb].to(DEV), lr=LR)
+        e_loss.append(loss); e_pred.append(pred)
+    tr = VideoTrainer(forked, subbatch_size=sb, lr=LR)
+    losses, preds = tr.train_video(aud, vis, lab)
+    torch.cuda.synchronize()
+    assert forked._side_stream is not None and ref._side_stream is None
+    assert torch.equal(losses, torch.cat(e_loss)) and torch.equal(preds, torch.cat(e_pred))
+    sd_r, sd_f = ref.state_dict(), forked.state_dict()
+    for k in sd_r:
+        assert torch.equal(sd_r[k], sd_f[k]), k
+    assert torch.equal(ref._garena, forked._garena)
+
+
 def test_three_graph_driven_steps_reproduce_the_reference_goldens():
     g = Golden("avm_a1_n10_h40_mask3")
     assert g.steps == 3 and g.n == 10
