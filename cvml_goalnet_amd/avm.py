@@ -128,9 +128,7 @@ class AVM(nn.Module):
         # cores with fp32 accumulation; statistics, master weights, parameter gradients and Adam stay fp32.
         # fp16 keeps 11 significand bits against bf16's 8 (~8 x less rounding noise in the logits) but has 5 exponent bits:
         # the activation gradients it stores need a loss scale (loss_scale, below) and an overflow guard.
-        self.precision = precision
-        self._half = precision in ("bf16", "fp16")
-        self._h16 = torch.float16 if precision == "fp16" else torch.bfloat16
+        self.precision = precision     # property: also sets _half / _h16
         # dL/dpred is multiplied by the loss scale before backward, the fused Adam divides it out again (a power of two: exact).
         # None (fp16 default) = 2^(10 + ceil(log2 n)) for a step of n frames: dL/dpred is O(1/n) and the 16-bit activation
         # gradients measured with scripts/grad_ranges.py (medians 6e-10 .. 1e-8, maxima 2e-7 .. 8e-6 at n = 1 024; ~1000 x that at
@@ -187,6 +185,19 @@ class AVM(nn.Module):
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
+
+    @property
+    def precision(self) -> str:
+        return self._precision
+
+    @precision.setter
+    def precision(self, value: str):
+        if value not in ("fp32", "bf16", "fp16"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+        self._precision = value
+        self._half = value in ("bf16", "fp16")
+        self._h16 = torch.float16 if value == "fp16" else torch.bfloat16     # the 16-bit storage format of the GEMM operands
+        self._w5b, self._w5b_version = None, None                              # a copy in the other format is not reusable
 
     # ------------------------------------------------------------------------------------------
     # parameter arena

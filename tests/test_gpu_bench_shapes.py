@@ -96,13 +96,15 @@ def _run_case(precision, h, n_unique, copies):
     with torch.no_grad():
         avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, aud, vis, masks, True, inter)
     ref_logit = inter["logit"].view(-1).clone()
-    nd, worst = routing_disagreements(inter, taps)
+    fp32 = precision == "fp32"
+    # 16-bit modes round the conv outputs, so their argmax differs from ATen's in thousands of windows by construction; the
+    # routing check (an unfold + top-2 over every window) is only meaningful — and only run — for the fp32 engine
+    nd, worst = routing_disagreements(inter, taps) if fp32 else (-1, float("nan"))
     del inter
     gc.collect()
     e_logit = (logit - ref_logit).abs()
     print(f"[parity] {precision} {n}x{h}x{h} ({copies} x {n_unique}): logit error vs CPU oracle mean {e_logit.mean():.2e} max {e_logit.max():.2e}; "
           f"{nd} max-pool windows routed differently (largest top-2 gap {worst:.2e} of max|y|)")
-    fp32 = precision == "fp32"
     if fp32:
         assert worst <= NEAR_TIE, "max-pool argmax differs from ATen's where the window is NOT a near-tie"
         if nd == 0:
@@ -185,10 +187,17 @@ def _run_case(precision, h, n_unique, copies):
     assert not failures, "\n".join(failures)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_bench_step_1024_frames_of_224_as_64_copies_of_a_16_frame_oracle_step(precision):
-    """the configuration bench.py times (BASELINE.json metric): 64 clips x 16 frames of 224 x 224"""
+    """the configuration bench.py times (BASELINE.json metric): 64 clips x 16 frames of 224 x 224; fp32 is the headline,
+    bf16 also covers BASELINE.json config 3's precision at twice its 512 frames"""
     _run_case(precision, 224, 16, 64)
+
+
+def test_fp16_step_of_2048_frames_of_224_as_128_copies():
+    """BASELINE.json config 5's per-GPU size (128-frame clips x 16 clips per GPU = 2 048 frames, fp16 MFMA): twice the bench
+    batch, every activation tensor beyond 2^32 bytes"""
+    _run_case("fp16", 224, 16, 128)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -198,15 +207,10 @@ def test_16bit_step_of_32_frames_forward_and_backward_vs_oracle(h, precision):
     _run_case(precision, h, 32, 1)
 
 
-def test_fp32_step_of_128_frames_of_224_as_8_copies(monkeypatch):
-    """BASELINE.json config 2's size (batch 8 clips = 128 frames, fp32, 1 GPU) on the fp32 engine"""
-    _run_case("fp32", 224, 16, 8)
-
-
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_16bit_logits_track_the_oracle_over_25_adam_steps_at_224(precision):
     """25 fused bf16 train steps on 32 frames of 224 x 224 (n > 16: the bf16 linear5 / p3 branches), probing the forward on
-    the current weights against the fp32 CPU oracle ON THOSE SAME WEIGHTS after 0, 5 and 25 steps. Adam moves every one of
+    the current weights against the fp32 CPU oracle ON THOSE SAME WEIGHTS after 0 and 25 steps. Adam moves every one of
     linear5's 2.5 M input weights per output by ~lr per step, so on the frames being trained the pre-sigmoid logit grows to
     O(10^2 - 10^3) within a few steps (measured: 530 after 5 steps, 2 500 after 25 — the reference never ran at 224 x 224);
     an absolute 1e-3 is then below bf16's resolution of the logit itself. Criterion: max-abs error <= 1e-3 while |logit| <= 1
@@ -218,7 +222,7 @@ def test_16bit_logits_track_the_oracle_over_25_adam_steps_at_224(precision):
     lab = torch.from_numpy(synth.make_labels(n))
     ag, vg, lg = aud.to(DEV), vis.to(DEV), lab.to(DEV)
     worst = []
-    for steps_done in (0, 5, 25):
+    for steps_done in (0, 25):
         while model._adam_t < steps_done:
             model.train_step(ag, vg, lg)
         sd = model.state_dict()
