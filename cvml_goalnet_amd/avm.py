@@ -669,7 +669,12 @@ class AVM(nn.Module):
         else:
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
             ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
-        self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
+        if i == 1:
+            # conv1's bias gradient is written a second time by goalnet_conv1_wgrad (on the main stream, later): keep this
+            # one on the main stream too so that the order of the two writers does not depend on the schedule
+            ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
+        else:
+            self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
         return dy
 
     def backward_device(self, ctx, dout, on_bucket=None):
