@@ -383,6 +383,9 @@ __device__ __forceinline__ void compute_tile(const float* la, const float* lb, f
 // correct and measured without gain, and removed again (git history): 4 MFMA-only consumer waves + 4 staging-only
 // producer waves per block (122), and LDS-DMA (`buffer_load ... lds`) staging of the operands that need no
 // transform (123-127): the cost follows the bytes moved into LDS, not the instruction mix of the MFMA waves.
+// Round 2: a two-deep register prefetch for the weight gradient (loads of K-tile kt + 2 issued before the MFMAs of tile kt,
+// two register sets and loader instances alternating; 248 VGPRs, no spill) measured 116.4 vs 116.6 TF/s at 128 frames:
+// memory latency is not what holds it at 0.69-0.74 of peak either. Removed.
 template <class AL, class BL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
