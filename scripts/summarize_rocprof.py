@@ -70,7 +70,7 @@ if agg:
             if b * 1024 < 1e6:
                 continue
             o.write(f"| `{k}` | {n} | {fe:.0f} | {wr:.0f} | {b * 1024 / 1e9:.3f} |\n")
-    for dt, prefix in (("f32", "gemm_f32_kernel<ConvALoader<true>"), ("bf16", "gemm_bf16_256_kernel<ConvAPadLoader256<64>, KCLoader256<32>, 0>")):
+    for dt, prefix in (("f32", "gemm_f32_kernel<ConvALoader<true>"), ("bf16", "gemm_bf16_256_kernel<ConvAPadLoader256<64>, KCLoader256<32>, 0, false>")):
         key = next((k for k in agg if k.startswith(prefix)), None)
         if not key:
             continue
