@@ -334,7 +334,50 @@ __device__ __forceinline__ void store_acc_h(const EpiP& ep, const f32x16 (&acc)[
         }
 }
 
-template <class AL, class BL, bool F16>
+// ---- narrow outputs (N <= 64: conv2's data gradient): block tile 128 x 64, the four waves stacked along M (32 rows x 64
+// columns each = 1 x 2 MFMA tiles); LDS images and loaders unchanged (rows 64..127 of the B tile are out of range -> zeros);
+// K-contiguous operands only. On the 128-wide tile half of every MFMA multiplied zero columns.
+template <bool F16>
+__device__ __forceinline__ void compute_tile_h_n64(const char* la, const char* lb, f32x16 (&acc)[2], int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(la + kc_boff(wave * 32 + r, 2 * ks + h));
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lb + kc_boff(r, 2 * ks + h));
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lb + kc_boff(32 + r, 2 * ks + h));
+        if constexpr (F16) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b0), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b1), acc[1], 0, 0, 0);
+        } else {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&acc)[2], int tm, int tn, int split, int wave, int lane) {
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+        const int col = tn * 64 + fn * 32 + r;
+        const bool colok = col < ep.cols;
+        const float bv = (mode == EPI_BIAS_RELU && ep.bias) ? ep.bias[colok ? col : 0] : 0.f;
+        const float lo = (mode == EPI_BIAS_RELU && ep.relu) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = (int64_t)tm * BM + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (!(colok && row < ep.rows)) continue;
+            const float v = acc[fn][e];
+            if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
+            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v + bv, lo);
+            else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
+        }
+    }
+}
+
+template <class AL, class BL, bool F16, bool N64 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                            int tiles_m, int tiles_n, int m_fast,
                                                            int ktiles, int ktiles_per_split) {
@@ -346,8 +389,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles, kt0 + ktiles_per_split);
 
+    static_assert(!N64 || (!AL::TR && !BL::TR), "the 128 x 64 tile reads K-contiguous LDS images");
     const AL al(ap, tm * BM, tid);
-    const BL bl(bp, tn * BN, tid);
+    const BL bl(bp, tn * (N64 ? 64 : BN), tid);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -372,11 +416,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
             al.issue(kt + 1, lds[cur ^ 1][0]);
             bl.issue(kt + 1, lds[cur ^ 1][1]);
         }
-        compute_tile_h<AL::TR, BL::TR, F16>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
+        if constexpr (N64) compute_tile_h_n64<F16>(lds[cur][0], lds[cur][1], acc[0], wave, lane);
+        else compute_tile_h<AL::TR, BL::TR, F16>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA data has landed before anyone passes the barrier
         __syncthreads();
     }
-    store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, split, wm, wn, lane);
+    if constexpr (N64) store_acc_h_n64(ep, acc[0], tm, tn, split, wave, lane);
+    else store_acc_h<AL::TR, BL::TR>(ep, acc, tm, tn, split, wm, wn, lane);
 }
 
 // A short reduction with a huge output (linear5 dW: 16 K-tiles, 5 GB written): the time goes into per-block latency
@@ -424,17 +470,17 @@ int launch_gemm_h_1stage(const char* name, const typename AL::P& ap, const typen
     return 0;
 }
 
-template <class AL, class BL>
+template <class AL, class BL, bool N64 = false>
 int launch_gemm_h(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
                   int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, bool f16, hipStream_t st) {
-    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + (N64 ? 64 : BN) - 1) / (N64 ? 64 : BN);
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
-    if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, true>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
+    if (f16) hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, true, N64>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
                                 ktiles, kps);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, false>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, false, N64>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast,
                             ktiles, kps);
     GN_LAUNCH_CHECK(name);
     return 0;
@@ -718,7 +764,9 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
                    "conv3x3_fwd_bf16p: workspace too small or misaligned");
         ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
     }
-    const int rc = launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, f16 != 0, st);
+    const int rc = (Cout <= 64 && !getenv("GOALNET_BF16_N64_OFF"))       // 128 x 64 tile (conv2's data gradient: 256 -> 64 channels)
+        ? launch_gemm_h<ConvAPadLoaderH, KCLoaderH, true>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, f16 != 0, st)
+        : launch_gemm_h<ConvAPadLoaderH, KCLoaderH>("conv3x3_fwd_bf16p", ap, bp, ep, M, Cout, 9 * Cin / BKH, nsplit, 0, f16 != 0, st);
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("conv3x3_fwd_bf16p.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }

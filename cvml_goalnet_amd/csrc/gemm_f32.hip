@@ -377,6 +377,48 @@ __device__ __forceinline__ void compute_tile(const float* la, const float* lb, f
     }
 }
 
+// ---- narrow outputs (N <= 64: conv2's data gradient has 64 output channels) -------------------------------------------------
+// On the 128-wide tile half of every MFMA multiplied zero columns (measured: 66 TF/s of useful work). N64: the block tile is
+// 128 x 64 — the four waves stack along M (32 rows each) and every wave computes 32 x 64 = 1 x 2 MFMA tiles; the LDS images and
+// the loaders are unchanged (the B loader's rows 64..127 are out of range and read zeros), only K-contiguous operands.
+__device__ __forceinline__ void compute_tile_n64(const float* la, const float* lb, f32x16 (&acc)[2], int wave, int r, int h) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4 ta = *reinterpret_cast<const float4*>(&la[kc_off(wave * 32 + r, 2 * s + h)]);
+        const float4 tb0 = *reinterpret_cast<const float4*>(&lb[kc_off(r, 2 * s + h)]);
+        const float4 tb1 = *reinterpret_cast<const float4*>(&lb[kc_off(32 + r, 2 * s + h)]);
+        const float a[4] = {ta.x, ta.y, ta.z, ta.w}, b0[4] = {tb0.x, tb0.y, tb0.z, tb0.w}, b1[4] = {tb1.x, tb1.y, tb1.z, tb1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[1], 0, 0, 0);
+        }
+    }
+}
+
+// epilogue of the 128 x 64 tile: D[row][col], col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void store_acc_n64(const EpiP& ep, const f32x16 (&acc)[2], int tm, int tn, int split, int wave, int r, int h) {
+    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn) {
+        const int col = tn * 64 + fn * 32 + r;
+        const bool colok = col < ep.cols;
+        const int64_t row0 = (int64_t)tm * BM + wave * 32 + 4 * h;
+        const float bv = (mode == EPI_BIAS_RELU && ep.bias) ? ep.bias[colok ? col : 0] : 0.f;
+        const float lo = (mode == EPI_BIAS_RELU && ep.relu) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+            if (!(colok && row < ep.rows)) continue;
+            const float v = acc[fn][e];
+            if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
+            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v + bv, lo);
+            else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
+        }
+    }
+}
+
 // ---- the kernel: 256 threads, every wave stages and computes, 2 blocks per CU ---------------------------------------
 // Measured ceilings on conv3 forward (scripts/bench_gemm.py, N = 128, 2.37 GHz): 147 TFLOP/s with no staging in the
 // loop, 135 with only the global loads or only the LDS writes, 127 with both. Two restructurings were built, found
@@ -386,7 +428,7 @@ __device__ __forceinline__ void compute_tile(const float* la, const float* lb, f
 // Round 2: a two-deep register prefetch for the weight gradient (loads of K-tile kt + 2 issued before the MFMAs of tile kt,
 // two register sets and loader instances alternating; 248 VGPRs, no spill) measured 116.4 vs 116.6 TF/s at 128 frames:
 // memory latency is not what holds it at 0.69-0.74 of peak either. Removed.
-template <class AL, class BL>
+template <class AL, class BL, bool N64 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split, int xcd_splits) {
@@ -410,8 +452,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles, kt0 + ktiles_per_split);
 
+    static_assert(!N64 || (AL::KC && BL::KC), "the 128 x 64 tile reads K-contiguous LDS images");
     AL al(ap, tm * BM, tid);
-    BL bl(bp, tn * BN, tid);
+    BL bl(bp, tn * (N64 ? 64 : BN), tid);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -443,7 +486,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
             al.issue(kt + 1, ra);
             bl.issue(kt + 1, rb);
         }
-        compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        if constexpr (N64) compute_tile_n64(lds[cur][0], lds[cur][1], acc[0], wave, r, h);
+        else compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
         if (more) {
             al.finish(ra);
             bl.finish(rb);
@@ -452,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
         }
         __syncthreads();
     }
-    store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
+    if constexpr (N64) store_acc_n64(ep, acc[0], tm, tn, split, wave, r, h);
+    else store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
 }
 
 // sums `nsplit` raw slabs (deterministic order) and applies the epilogue. cols % 4 == 0.
@@ -507,10 +552,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* sl
     }
 }
 
-template <class AL, class BL>
+template <class AL, class BL, bool N64 = false>
 int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P& bp, const EpiP& ep,
                 int64_t M, int64_t N, int ktiles, int nsplit, int m_fast, hipStream_t st) {
-    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + (N64 ? 64 : BN) - 1) / (N64 ? 64 : BN);
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
@@ -518,7 +563,7 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     const bool xcd_local = nsplit >= 8 && tiles_m * tiles_n <= 256 && tiles_m * tiles_n * ((nsplit + 7) / 8 * 8) < (1ll << 31);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
     if (xcd_local) grid = dim3((unsigned)(tiles_m * tiles_n * ((nsplit + 7) / 8 * 8)), 1, 1);
-    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+    hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, N64>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
                        m_fast, ktiles, kps, xcd_local ? nsplit : 0);
     GN_LAUNCH_CHECK(name);
     return 0;
@@ -600,12 +645,15 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
         ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
     }
     int rc;
+    const bool narrow = Cout <= 64 && !getenv("GOALNET_F32_N64_OFF");       // 128 x 64 tile (conv2's data gradient: 256 -> 64 channels)
     if (scale) {
         ConvALoader<true>::P ap{x, H, W, Cin, M, scale, shift};
-        rc = launch_gemm<ConvALoader<true>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
+        rc = narrow ? launch_gemm<ConvALoader<true>, KCLoader<false>, true>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st)
+                    : launch_gemm<ConvALoader<true>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
     } else {
         ConvALoader<false>::P ap{x, H, W, Cin, M, nullptr, nullptr};
-        rc = launch_gemm<ConvALoader<false>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
+        rc = narrow ? launch_gemm<ConvALoader<false>, KCLoader<false>, true>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st)
+                    : launch_gemm<ConvALoader<false>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
     }
     if (rc || nsplit == 1) return rc;
     return launch_splitk_reduce("conv3x3_fwd.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);

@@ -59,7 +59,8 @@ def test_fp16_conversions_bit_exact_and_subnormal_operands_survive_the_mfma():
 
 @pytest.mark.parametrize("tile", ["128", "256"])
 @pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [(3, 13, 13, 64, 256, True, True), (16, 11, 11, 512, 256, False, False),
-                                                     (9, 40, 36, 64, 320, True, True), (3, 7, 7, 64, 260, False, False)])
+                                                     (9, 40, 36, 64, 320, True, True), (3, 7, 7, 64, 260, False, False),
+                                                     (5, 13, 13, 256, 64, False, False)])          # 128 x 64 tile
 def test_conv3x3_fp16_forward_and_data_gradient(n, h, w, cin, cout, bias, relu, tile, monkeypatch):
     monkeypatch.setenv("GOALNET_BF16_TILE", tile)
     x = rnd(n, h, w, cin, seed=163)

@@ -106,6 +106,9 @@ def test_conv1_fwd_and_wgrad(n, h, w, monkeypatch):
     (16, 11, 11, 512, 256, False, False, False),# M = 1936: 16 M-tiles, ragged last tile
     (16, 11, 11, 256, 512, True, True, True),
     (1, 3, 3, 64, 128, True, False, True),
+    (40, 26, 22, 256, 64, False, False, False), # 128 x 64 tile at M = 22 880 pixels (179 M-tiles, ragged last one), no split-K
+    (3, 9, 7, 64, 32, True, True, True),        # 128 x 64 tile: 32 of its 64 columns valid, BatchNorm on the load, bias + ReLU
+    (2, 5, 5, 128, 60, False, True, False),     # 60 columns (Cout % 4 == 0 is all the entry point asks)
 ])
 def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
     x = rnd(n, h, w, cin, seed=7)
@@ -429,6 +432,7 @@ def test_to_bf16_padded_layout_exact():
     (2, 7, 5, 64, 256, True, True), (3, 13, 13, 64, 256, True, True), (16, 11, 11, 256, 512, True, True),
     (16, 11, 11, 512, 256, False, False), (2, 13, 13, 256, 64, False, False), (9, 40, 36, 64, 320, True, True),
     (1, 7, 5, 64, 256, True, True), (3, 7, 7, 64, 260, False, False),      # 35 / 147 pixels: the last quad of rows is only partly valid
+    (40, 26, 22, 256, 64, False, False), (3, 9, 7, 64, 32, True, True),    # <= 64 output channels: the 128 x 64 tile (tile "128")
 ])
 def test_conv3x3_fwd_bf16_padded_input(n, h, w, cin, cout, bias, relu, tile, monkeypatch):
     monkeypatch.setenv("GOALNET_BF16_TILE", tile)         # read by the entry point at call time; unset = chosen by size
