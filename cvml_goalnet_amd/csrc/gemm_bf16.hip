@@ -772,7 +772,7 @@ int goalnet_conv3x3_fwd_bf16p(const void* x_pad, const void* w_bf16, const float
 }
 
 }  // extern "C"
-template <class AL, class BL> static const char* gemm_bf16_kernel_name() { return __PRETTY_FUNCTION__; }
+template <class AL, class BL, bool F16, bool N64> static const char* gemm_bf16_kernel_name() { return __PRETTY_FUNCTION__; }
 extern "C" {
 
 /* which kernel goalnet_conv3x3_fwd_bf16p(_o16) launches for these dims with a bias / ReLU epilogue (forward == 1) or a raw
@@ -780,7 +780,8 @@ extern "C" {
 const char* goalnet_conv3x3_fwd_bf16p_kernel_name(int N, int H, int W, int Cin, int Cout, int forward) {
     (void)Cin;
     if (conv_use_256((int64_t)N * H * W, Cout)) return conv_bf16_256_kernel_name(forward ? 0 : 1);
-    return gemm_bf16_kernel_name<ConvAPadLoaderH, KCLoaderH>();
+    return (Cout <= 64 && !getenv("GOALNET_BF16_N64_OFF")) ? gemm_bf16_kernel_name<ConvAPadLoaderH, KCLoaderH, false, true>()
+                                                            : gemm_bf16_kernel_name<ConvAPadLoaderH, KCLoaderH, false, false>();
 }
 
 /* 1 when goalnet_conv3x3_fwd_bf16p_o16 serves these dims (the shapes the 256 x 256 tile takes), else 0 */

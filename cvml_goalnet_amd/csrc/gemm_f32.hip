@@ -662,15 +662,17 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
 }  // extern "C"
 namespace {
 // the kernel template a launch_gemm<AL, BL> call instantiates, as the compiler spells its arguments
-template <class AL, class BL> const char* gemm_f32_kernel_name() { return __PRETTY_FUNCTION__; }
+template <class AL, class BL, bool N64> const char* gemm_f32_kernel_name() { return __PRETTY_FUNCTION__; }
 }
 extern "C" {
 
 /* which kernel goalnet_conv3x3_fwd launches for these dims (the dispatch above, not executed): bench.py names its roofline
  * kernel from this instead of a hard-coded string */
 const char* goalnet_conv3x3_fwd_kernel_name(int N, int H, int W, int Cin, int Cout, int affine) {
-    (void)N; (void)H; (void)W; (void)Cin; (void)Cout;
-    return affine ? gemm_f32_kernel_name<ConvALoader<true>, KCLoader<false>>() : gemm_f32_kernel_name<ConvALoader<false>, KCLoader<false>>();
+    (void)N; (void)H; (void)W; (void)Cin;
+    const bool narrow = Cout <= 64 && !getenv("GOALNET_F32_N64_OFF");       // as in goalnet_conv3x3_fwd
+    if (affine) return narrow ? gemm_f32_kernel_name<ConvALoader<true>, KCLoader<false>, true>() : gemm_f32_kernel_name<ConvALoader<true>, KCLoader<false>, false>();
+    return narrow ? gemm_f32_kernel_name<ConvALoader<false>, KCLoader<false>, true>() : gemm_f32_kernel_name<ConvALoader<false>, KCLoader<false>, false>();
 }
 
 static int wgrad_splits(int64_t M, int Cin, int Cout) {
