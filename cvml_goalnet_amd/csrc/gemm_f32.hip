@@ -441,9 +441,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
         // fetched into that XCD's L2 once and re-hit by the other tiles, instead of once per XCD (profiles/r02_traffic.md)
         const int tiles = tiles_m * tiles_n;
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        split = (j / tiles) * 8 + xcd;
+        int t;
+        if (tiles > 64 && tiles <= 128) {
+            // conv3's weight gradient has 72 tiles per split but an XCD holds 64 blocks: in plain order every round of 64 mixes
+            // the tail of one split with the head of the next (two pixel ranges streaming through the L2 at once). Two-phase
+            // order: first, per split, the 64 tiles that fill the XCD exactly (one pixel range at a time); then the remaining
+            // tiles - 64 of all of the XCD's splits together.
+            const int gs = (xcd_splits + 7) / 8, rest = tiles - 64, nA = gs * 64;
+            int q;
+            if (j < nA) { q = j >> 6; t = j & 63; }
+            else { const int i = j - nA; q = i / rest; t = 64 + (i - q * rest); }
+            split = q * 8 + xcd;
+        } else {
+            split = (j / tiles) * 8 + xcd;
+            t = j - (j / tiles) * tiles;
+        }
         if (split >= xcd_splits) return;                  // the grid is padded to whole groups of 8 splits
-        const int t = j - (j / tiles) * tiles;
         if (m_fast) { tm = t % tiles_m; tn = t / tiles_m; } else { tn = t % tiles_n; tm = t / tiles_n; }
     } else {
         tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
