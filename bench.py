@@ -385,11 +385,20 @@ def main():
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     import torch.distributed as dist
     distributed = world > 1 or os.environ.get("GOALNET_DDP_FORCE") == "1"
+    # GOALNET_BENCH_BACKEND=gloo: REHEARSAL of the N > 1 path on a one-GPU box — every rank uses cuda:0 and gloo carries the device
+    # tensors through the host (RCCL needs one GPU per rank). Exercises everything of the multi-rank bench but RCCL itself; its
+    # numbers mean nothing.
+    backend = os.environ.get("GOALNET_BENCH_BACKEND", "nccl")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "gloo":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -431,7 +440,8 @@ def main():
             model.forward_device(aud[:2] if aud is not None else None, vis[:2], save=False)      # materialise + sync_params
         probe, bucket_bytes = comm_probe(model, dev, world)
         sharded = model.grad_sync.sharded(model)
-        comm = {"ranks": world, "backend": "nccl (RCCL over xGMI)", "bucket_bytes": bucket_bytes,
+        comm = {"ranks": world, "backend": "nccl (RCCL over xGMI)" if backend == "nccl" else "gloo (rehearsal on one GPU: not a measurement)",
+                "bucket_bytes": bucket_bytes,
                 "mode": ("bucket 1 (linear5.weight): reduce-scatter -> Adam on the rank's 1/%d slice -> asynchronous all-gather of the "
                          "updated weights (waited for before the next step's linear5); buckets 0, 2: all-reduce" % world) if sharded
                         else "all-reduce of three buckets overlapped with backward, replicated fused Adam",

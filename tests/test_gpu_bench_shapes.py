@@ -200,10 +200,10 @@ def test_fp16_step_of_2048_frames_of_224_as_128_copies():
     _run_case("fp16", 224, 16, 128)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("h", [224, 40])
+@pytest.mark.parametrize("h,precision", [(224, "bf16"), (40, "bf16"), (40, "fp16")])
 def test_16bit_step_of_32_frames_forward_and_backward_vs_oracle(h, precision):
-    """n > 16: linear5 / p3 / y3 / dbn3 on their 16-bit forms (avm.py forward_device: bf5, p16_3, y16_3; backward: o16_3)"""
+    """n > 16: linear5 / p3 / y3 / dbn3 on their 16-bit forms (avm.py forward_device: bf5, p16_3, y16_3; backward: o16_3).
+    fp16 at 224 x 224 runs the same branches in the 2 048-frame test above and at 16 frames in tests/test_gpu_fp16.py."""
     _run_case(precision, h, 32, 1)
 
 
