@@ -918,7 +918,10 @@ class AVM(nn.Module):
         linear5.weight (ddp.py) the pass covers this rank's slice only — three launches — and the optimizer state exists
         only for what the rank owns."""
         segs = self._adam_segments()
-        if self._adam_m is None or self._adam_segs != segs:
+        if self._adam_m is not None and self._adam_segs != segs:
+            raise GoalnetError("the optimizer state was laid out for another sharding of linear5.weight; attach / detach "
+                               "ddp.GradSync(shard_linear5=True) before the first optimizer step, not between steps")
+        if self._adam_m is None:
             total = sum(hi - lo for lo, hi in segs)
             self._adam_m = torch.zeros(total, dtype=F32, device=self._device)
             self._adam_v = torch.zeros(total, dtype=F32, device=self._device)
