@@ -184,6 +184,11 @@ class AVM(nn.Module):
         self._side_stream = None
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
+        # larger steps fork too (GOALNET_OVERLAP_LARGE=0: never): there the point is to run HBM-bound passes (the fused Adam over
+        # linear5.weight, the BatchNorm / pool backward of the next block, linear5's 5 GB weight-gradient store) UNDER the
+        # MFMA-bound convolution gradients instead of after them
+        self.overlap_large = os.environ.get("GOALNET_OVERLAP_LARGE", "1") != "0"
+        self.time_labels = None        # bench: with kernel_events set, time only these labels (None = all, and no forking)
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
     @property
@@ -455,7 +460,7 @@ class AVM(nn.Module):
 
     def _timed(self, label, flops, fn, *args):
         """Run one kernel launch; when bench.py asked for it, bracket it with HIP events on the launching stream."""
-        if self.kernel_events is None:
+        if self.kernel_events is None or (self.time_labels is not None and label not in self.time_labels):
             return fn(*args)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -475,6 +480,13 @@ class AVM(nn.Module):
         row = torch.empty(width, dtype=torch.float64, device=self._device)
         ops.partials_sum_f64(partials, width, row)
         return self.stat_sync.all_reduce(row)
+
+    def _fork_ok(self, n):
+        """side-stream overlap for this step? Not while every kernel is being timed (bench's instrumented steps: an overlapped
+        kernel's bracket would measure its neighbours too)."""
+        if self.kernel_events is not None and self.time_labels is None:
+            return False
+        return n <= self.overlap_rows or self.overlap_large
 
     @staticmethod
     def _bwd16_ok(wc):
@@ -537,7 +549,7 @@ class AVM(nn.Module):
         cat = torch.empty(n, fw, dtype=F32, device=dev)          # torch.cat((audio, visual), -1), utils.py:266
         mcat = torch.empty(n, fw, dtype=F32, device=dev) if save else None
         a1 = a2 = None
-        ffork = _Fork(self, n <= self.overlap_rows and self.kernel_events is None and self.audio_included)
+        ffork = _Fork(self, self._fork_ok(n) and self.audio_included)
         if self.audio_included:
             # ---- AudBl, utils.py:214-227: independent of VisBl until the concatenation -> side stream for small steps (_Fork)
             a1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
@@ -677,9 +689,11 @@ class AVM(nn.Module):
             self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
         return dy
 
-    def backward_device(self, ctx, dout, on_bucket=None):
+    def backward_device(self, ctx, dout, on_bucket=None, after_linear5=None):
         """dout (N,) GPU. Fills the gradient arena (every slot is overwritten). `on_bucket(k)` is called when
-        bucket k of ddp.bucket_slices() is complete (0: fusion+audbl+linear5.bias, 1: linear5.weight, 2: rest)."""
+        bucket k of ddp.bucket_slices() is complete (0: fusion+audbl+linear5.bias, 1: linear5.weight, 2: rest).
+        `after_linear5(fork)`: called once linear5's weight gradient (side stream) and data gradient (main stream) are both
+        enqueued — from there on nothing reads linear5.weight or its 16-bit copy again in this step (train_step's early Adam)."""
         self._ensure_garena()
         dev = self._device
         n, h, w = ctx["n"], ctx["h"], ctx["w"]
@@ -687,7 +701,7 @@ class AVM(nn.Module):
         P, G = self._pflat, self._gflat
         hs, ms = ctx["hs"], ctx["ms"]
         # small steps: weight / bias gradients and the AudBl branch run on a side stream under the dX chain (_Fork)
-        fork = self._fork = _Fork(self, n <= self.overlap_rows and self.kernel_events is None and dout.is_cuda)
+        fork = self._fork = _Fork(self, self._fork_ok(n) and dout.is_cuda)
 
         def bucket_done(k):
             if on_bucket:
@@ -750,10 +764,14 @@ class AVM(nn.Module):
                 ops.linear_bwd_dx_bf16_o16(dz5b, ctx["w5b"], dbn3.view(n, k5))
             else:
                 ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
+            if after_linear5:
+                after_linear5(fork)
         else:
             fork.run(lambda: ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512), dz)
             bucket_done(1)
             ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
+            if after_linear5:
+                after_linear5(fork)
 
         # block 3 (utils.py:184-187)
         dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
@@ -880,7 +898,18 @@ class AVM(nn.Module):
         self._arena_grad_scale = lscale
         if lscale != 1.0:
             ops.scale_(dout.view(-1), lscale)               # fp16: every activation gradient downstream carries this factor
-        self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None)
+        # One GPU, no gradient exchange, no overflow guard to consult: linear5.weight (99.8 % of the parameters at 224 x 224) gets
+        # its Adam pass the moment its gradient exists and its last reader of the step (the data gradient) is enqueued — on the
+        # side stream, i.e. 36 GB of HBM traffic under the MFMA-bound convolution gradients that follow instead of after them
+        early = sync is None and self.precision != "fp16" and self._fork_ok(n)
+        done_early = []
+
+        def early_adam(fork):
+            s5 = self.spec("visbl.linear5.weight")
+            fork.run(lambda: self._adam_range(s5.offset, s5.offset + s5.numel, lr, betas, eps, 1.0 / lscale))
+            done_early.append((s5.offset, s5.offset + s5.numel))
+        self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None,
+                             after_linear5=early_adam if early else None)
         scale = 1.0
         if sync is not None:
             scale = sync.finish(self)
@@ -892,7 +921,7 @@ class AVM(nn.Module):
             after = min(s.offset for s in self._specs if s.offset > s5.offset)
             ops.grad_finite_check(self._garena[after:], self._state[0], self._guard[0], self._guard[1])
             guard = self._guard[0]
-        self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard)
+        self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard, _done=done_early)
         ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
@@ -912,11 +941,7 @@ class AVM(nn.Module):
             return float(self.loss_scale)
         return float(2 ** (10 + max(0, math.ceil(math.log2(max(n, 1))))))
 
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True, _guard=None):
-        """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
-        counter state[0] (= completed steps) + 1, so the same captured launch serves every step. With a sharded
-        linear5.weight (ddp.py) the pass covers this rank's slice only — three launches — and the optimizer state exists
-        only for what the rank owns."""
+    def _adam_state(self):
         segs = self._adam_segments()
         if self._adam_m is not None and self._adam_segs != segs:
             raise GoalnetError("the optimizer state was laid out for another sharding of linear5.weight; attach / detach "
@@ -926,7 +951,40 @@ class AVM(nn.Module):
             self._adam_m = torch.zeros(total, dtype=F32, device=self._device)
             self._adam_v = torch.zeros(total, dtype=F32, device=self._device)
             self._adam_segs = segs
+        return segs
+
+    def _adam_range(self, lo, hi, lr, betas, eps, grad_scale):
+        """the fused Adam on arena[lo:hi] (unsharded optimizer state: moments live at the arena's offsets); refreshes the part of
+        the 16-bit copy of linear5.weight that lies inside. The step counter is NOT advanced (train_step does that once)."""
+        segs = self._adam_state()
+        assert segs == [(0, self._arena_numel)]
+        s5 = self.spec("visbl.linear5.weight")
+        p, g, m, v = self._arena[lo:hi], self._garena[lo:hi], self._adam_m[lo:hi], self._adam_v[lo:hi]
+        a, b = max(lo, s5.offset), min(hi, s5.offset + s5.numel)
+        if self._w5b is not None and self._w5b_version == self._w5_version() and a < b:
+            ops.adam_step_dev_shadow(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0],
+                                     self._w5b[a - s5.offset:b - s5.offset], a - lo, grad_scale, step_bias=1)
+        else:
+            ops.adam_step_dev(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0], grad_scale, step_bias=1)
+
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, _tick=True, _guard=None, _done=()):
+        """torch.optim.Adam defaults over the whole arena in one launch (main.py:70, 193). The step count is the device
+        counter state[0] (= completed steps) + 1, so the same captured launch serves every step. With a sharded
+        linear5.weight (ddp.py) the pass covers this rank's slice only — three launches — and the optimizer state exists
+        only for what the rank owns."""
+        segs = self._adam_state()
         self._adam_t += 1
+        if _done:
+            # ranges train_step already updated under backward (the early Adam on linear5.weight): the rest of the arena now
+            assert segs == [(0, self._arena_numel)] and _guard is None
+            cur = 0
+            for lo, hi in sorted(_done) + [(self._arena_numel, self._arena_numel)]:
+                if cur < lo:
+                    self._adam_range(cur, lo, lr, betas, eps, grad_scale)
+                cur = hi
+            if _tick:
+                ops.counter_add(self._state[0], 1)
+            return
         s5 = self.spec("visbl.linear5.weight")
         shadow_ok = self._w5b is not None and self._w5b_version == self._w5_version()
         off = 0

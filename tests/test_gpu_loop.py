@@ -164,7 +164,7 @@ def test_side_stream_overlap_changes_nothing_but_the_schedule(precision):
     h, sb = 40, 10
     aud, vis, lab = _video(47, h, True, 21)
     ref, forked = load_model(h, True, precision), load_model(h, True, precision)
-    ref.overlap_rows = 0                                                  # everything on the current stream
+    ref.overlap_rows, ref.overlap_large = 0, False                        # everything on the current stream, Adam after backward
     e_loss, e_pred = [], []
     for a in range(0, 47, sb):
         loss, pred = ref.train_step(aud[a:a + sb].to(DEV), vis[a:a + sb].to(DEV), lab[a:a + sb].to(DEV), lr=LR)
