@@ -184,10 +184,11 @@ class AVM(nn.Module):
         self._side_stream = None
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
-        # larger steps fork too (GOALNET_OVERLAP_LARGE=0: never): there the point is to run HBM-bound passes (the fused Adam over
-        # linear5.weight, the BatchNorm / pool backward of the next block, linear5's 5 GB weight-gradient store) UNDER the
-        # MFMA-bound convolution gradients instead of after them
-        self.overlap_large = os.environ.get("GOALNET_OVERLAP_LARGE", "1") != "0"
+        # GOALNET_OVERLAP_LARGE=1: fork at every size AND run the fused Adam over linear5.weight on the side stream as soon as its
+        # gradient exists (train_step's "early Adam") — HBM-bound passes under the MFMA-bound convolution gradients. Built,
+        # bit-identical, and measured WITHOUT gain (1 024 frames @224: fp32 449 -> 453 ms, bf16 78.7 -> 78.6 ms; 10 frames @40:
+        # 845 -> 974 us, the 0.66 GB Adam stream slows every small kernel it runs beside): off by default
+        self.overlap_large = os.environ.get("GOALNET_OVERLAP_LARGE", "0") == "1"
         self.time_labels = None        # bench: with kernel_events set, time only these labels (None = all, and no forking)
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
@@ -901,7 +902,7 @@ class AVM(nn.Module):
         # One GPU, no gradient exchange, no overflow guard to consult: linear5.weight (99.8 % of the parameters at 224 x 224) gets
         # its Adam pass the moment its gradient exists and its last reader of the step (the data gradient) is enqueued — on the
         # side stream, i.e. 36 GB of HBM traffic under the MFMA-bound convolution gradients that follow instead of after them
-        early = sync is None and self.precision != "fp16" and self._fork_ok(n)
+        early = sync is None and self.precision != "fp16" and self.overlap_large and self._fork_ok(n)
         done_early = []
 
         def early_adam(fork):

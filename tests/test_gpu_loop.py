@@ -157,14 +157,15 @@ def test_bf16_graph_loop_survives_writers_outside_the_graph():
         assert torch.equal(sd_e[k], sd_g[k]), k
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
-def test_side_stream_overlap_changes_nothing_but_the_schedule(precision):
+@pytest.mark.parametrize("precision,large", [("fp32", False), ("bf16", False), ("fp16", False), ("fp32", True), ("bf16", True)])
+def test_side_stream_overlap_changes_nothing_but_the_schedule(precision, large):
     """Small steps fork their weight-gradient / bias-gradient / AudBl kernels onto a second HIP stream (avm._Fork). Same kernels,
     same order inside every dependency chain: eager and graph-driven results must equal the single-stream run bit for bit."""
     h, sb = 40, 10
     aud, vis, lab = _video(47, h, True, 21)
     ref, forked = load_model(h, True, precision), load_model(h, True, precision)
     ref.overlap_rows, ref.overlap_large = 0, False                        # everything on the current stream, Adam after backward
+    forked.overlap_large = large                                          # True: also the early Adam on linear5.weight (off by default)
     e_loss, e_pred = [], []
     for a in range(0, 47, sb):
         loss, pred = ref.train_step(aud[a:a + sb].to(DEV), vis[a:a + sb].to(DEV), lab[a:a + sb].to(DEV), lr=LR)
