@@ -22,6 +22,8 @@ struct EpiP {
     float* mult_out; int64_t ldmo;        // (pre-activation > 0) * mul, saved for backward
     int64_t slab_stride;                  // > 0: raw partial sums to out + split * slab_stride (ld = cols)
     void* out16;                          // non-null (256^2 bf16 kernel, raw epilogue only): the result as bf16 [rows][ld] instead of `out`
+    // splitk_reduce only (fp32 conv weight gradient): out[row][col] -= corr_sh[col % corr_C] * corr_u[row * 9 + col / corr_C]
+    const float* corr_u; const float* corr_sh; int corr_C;
 };
 
 __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {

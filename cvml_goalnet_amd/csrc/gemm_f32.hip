@@ -254,30 +254,39 @@ struct ConvALoader {
 // B operand of the weight gradient: B(col = (tap, ci), red = m) = bnapply(x)[pixel m shifted by tap][ci].
 // Tap validity comes from a per-pixel border-code byte (bit0 h==0, bit1 h==H-1, bit2 w==0, bit3 w==W-1) prepared by
 // border_codes_kernel, so the loop needs no division; the resource is re-based per K-tile W+1 pixels in front of it.
+// The codes act on the ADDRESS (a padding tap loads from an out-of-range offset and reads 0), never on the data: the first
+// version zeroed the loaded values instead (16 selects + 4 byte loads per thread and K-tile) and the fp32 MFMA, which shares
+// its issue slots with every vector instruction, ran at 112 TF/s against 136 with the selects compiled out (conv3, 128 frames).
+// With the affine the zero of a padding tap becomes `shift[ci]`, i.e. the GEMM accumulates shift[ci] * dy[m][co] for every
+// (pixel, tap) whose tap falls into the padding; that term is a rank-one product of shift with sums of dy over border pixels
+// (wgrad_border_sums_kernel below) and the slab reduction subtracts it (EpiP::corr_*). It only involves the 2 (H + W) - 4
+// border pixels of a frame, so nothing cancels: the correction is ~5 % of the accumulated magnitude.
+// codes4[kt * 8 + k0] packs the codes of the four pixels kt * 32 + k0 + 8 i one thread loads of a K-tile; the word for the
+// next K-tile is fetched one K-tile ahead.
 template <bool AFFINE>
 struct ConvWgradBLoader {
     struct P {
         const float* x; int H, W, C; int M;
         const float* scale; const float* shift;
-        const uint8_t* codes;
+        const uint32_t* codes4;
     };
     static constexpr bool KC = false;
     const float* x;
     __amdgpu_buffer_rsrc_t rcodes;
-    int W, C, M, k0, tapshift;
-    unsigned voff[4], badmask, code4;
-    bool colok;
+    int W, C, M, k0, tapshift, nextkt;
+    unsigned voff[4], bad4, nextcode;
     float4 sc, sh;
     __device__ ConvWgradBLoader(const P& p, int col0, int tid) {
         const int col = col0 + (tid & 31) * 4;
-        colok = col < 9 * p.C;
+        const bool colok = col < 9 * p.C;
         const int cc = colok ? col : 0;
         const int tap = cc / p.C, ci = cc - tap * p.C;
         const int kh = tap / 3, kw = tap - 3 * kh;
         x = p.x; W = p.W; C = p.C; M = p.M; k0 = tid >> 5;
-        rcodes = make_rsrc(p.codes, (uint32_t)((p.M + 31) / 32 * 32));   // the range check covers voffset + soffset here
-        badmask = (kh == 0 ? 1u : 0u) | (kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : 0u) | (kw == 2 ? 8u : 0u);
+        rcodes = make_rsrc(p.codes4, (uint32_t)((p.M + 31) / 32 * 32));
+        bad4 = ((kh == 0 ? 1u : 0u) | (kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : 0u) | (kw == 2 ? 8u : 0u)) * 0x01010101u;
         tapshift = kh * p.W + kw;
+        nextkt = -1; nextcode = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) voff[i] = colok ? (unsigned)(((k0 + 8 * i + tapshift) * p.C + ci) * 4) : OOB;
         if (AFFINE) {
@@ -285,38 +294,98 @@ struct ConvWgradBLoader {
             sh = *reinterpret_cast<const float4*>(p.shift + ci);
         }
     }
+    __device__ __forceinline__ unsigned load_code(int kt) const {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rcodes, k0 * 4, kt * 32, 0);    // past the table: 0 (never consumed)
+    }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
         const int mbase = kt * BK;
-        // pixels [mbase - (W+1), mbase + 32 + (W+1)) clipped to the tensor: taps past the end are out of range (0);
-        // in-tensor padding taps are zeroed in finish() by the border code
+        const unsigned bad = (nextkt == kt ? nextcode : load_code(kt)) & bad4;      // pixels >= M carry 0xF: every tap bad
+        // pixels [mbase - (W+1), mbase + 32 + (W+1)) clipped to the tensor: taps past the end are out of range (0)
         const int64_t lead = (int64_t)mbase - (W + 1);
         const int64_t last = (int64_t)mbase + BK + (W + 1) < M ? (int64_t)mbase + BK + (W + 1) : M;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + lead * C, clamp_u32((last - lead) * C * 4));
         if (lead < 0) {      // first K-tiles only (wave-uniform): never touch memory in front of the tensor
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = bload(rx, mbase + k0 + 8 * i + tapshift < W + 1 ? OOB : voff[i], 0);
+            for (int i = 0; i < 4; ++i)
+                r[i] = bload(rx, (mbase + k0 + 8 * i + tapshift < W + 1 || ((bad >> (8 * i)) & 0xFFu)) ? OOB : voff[i], 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = bload(rx, voff[i], 0);
+            for (int i = 0; i < 4; ++i) r[i] = bload(rx, ((bad >> (8 * i)) & 0xFFu) ? OOB : voff[i], 0);
         }
-        code4 = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)      // codes[] is padded to a multiple of 32 entries, pixels >= M carry 0xF
-            code4 |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rcodes, (int)(k0 + 8 * i), mbase, 0) << (8 * i);
+        nextcode = load_code(kt + 1);
+        nextkt = kt + 1;
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
+        if (AFFINE) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool v = colok && (((code4 >> (8 * i)) & badmask) == 0);
-            r[i] = f4sel(v, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+            for (int i = 0; i < 4; ++i) r[i] = f4fma(r[i], sc, sh);
         }
     }
 };
 
-__global__ __launch_bounds__(256) void border_codes_kernel(uint8_t* __restrict__ codes, int M, int Mpad, int H, int W) {
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < Mpad; m += gridDim.x * blockDim.x) {
-        const int w = m % W, h = (m / W) % H;
-        codes[m] = m < M ? (uint8_t)((h == 0 ? 1 : 0) | (h == H - 1 ? 2 : 0) | (w == 0 ? 4 : 0) | (w == W - 1 ? 8 : 0)) : (uint8_t)0xF;
+// codes4[kt * 8 + k0] = codes of pixels kt * 32 + k0 + 8 i in byte i; code bits: 1 h==0, 2 h==H-1, 4 w==0, 8 w==W-1; pixels >= M: 0xF
+__global__ __launch_bounds__(256) void border_codes_kernel(uint32_t* __restrict__ codes4, int M, int Mpad, int H, int W) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Mpad / 4; j += gridDim.x * blockDim.x) {
+        const int kt = j >> 3, k0 = j & 7;
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = kt * 32 + k0 + 8 * i;
+            const int w = m % W, h = (m / W) % H;
+            const uint32_t c = m < M ? (uint32_t)((h == 0 ? 1 : 0) | (h == H - 1 ? 2 : 0) | (w == 0 ? 4 : 0) | (w == W - 1 ? 8 : 0)) : 0xFu;
+            word |= c << (8 * i);
+        }
+        codes4[j] = word;
+    }
+}
+
+// Sums of dy over the border pixels of every frame, per output channel: [0] row h = 0, [1] row h = H-1, [2] column w = 0,
+// [3] column w = W-1, [4..7] the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1). One block per frame (fp64 sums, one row of
+// 8 x Cout per frame), added up over the frames in a fixed order by wgrad_border_u_kernel, which also forms
+// U[co][tap] = sum of dy[m][co] over the pixels m at which `tap` falls into the zero padding (inclusion - exclusion).
+__global__ __launch_bounds__(256) void wgrad_border_sums_kernel(const float* __restrict__ dy, double* __restrict__ parts,
+                                                               int H, int W, int Cout) {
+    const int n = blockIdx.x;
+    const float* f = dy + (int64_t)n * H * W * Cout;
+    double* out = parts + (int64_t)n * 8 * Cout;
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+        double r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        for (int w = 0; w < W; ++w) { r0 += (double)f[(int64_t)w * Cout + c]; r1 += (double)f[((int64_t)(H - 1) * W + w) * Cout + c]; }
+        for (int h = 0; h < H; ++h) { c0 += (double)f[(int64_t)h * W * Cout + c]; c1 += (double)f[((int64_t)h * W + W - 1) * Cout + c]; }
+        out[0 * Cout + c] = r0; out[1 * Cout + c] = r1; out[2 * Cout + c] = c0; out[3 * Cout + c] = c1;
+        out[4 * Cout + c] = (double)f[c];
+        out[5 * Cout + c] = (double)f[(int64_t)(W - 1) * Cout + c];
+        out[6 * Cout + c] = (double)f[(int64_t)(H - 1) * W * Cout + c];
+        out[7 * Cout + c] = (double)f[((int64_t)(H - 1) * W + W - 1) * Cout + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_border_u_kernel(const double* __restrict__ parts, int N, int Cout, float* __restrict__ u) {
+    __shared__ double s[32][8];
+    const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (c < Cout) {
+        const double* q = parts + (int64_t)j * Cout + c;
+        int n = 0;
+        for (; n + 3 < N; n += 4) {
+            a0 += q[(int64_t)n * 8 * Cout]; a1 += q[(int64_t)(n + 1) * 8 * Cout];
+            a2 += q[(int64_t)(n + 2) * 8 * Cout]; a3 += q[(int64_t)(n + 3) * 8 * Cout];
+        }
+        for (; n < N; ++n) a0 += q[(int64_t)n * 8 * Cout];
+    }
+    s[cl][j] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * 9; t += 256) {
+        const int cc = t / 9, tap = t - 9 * cc, kh = tap / 3, kw = tap - 3 * kh;
+        if (blockIdx.x * 32 + cc >= Cout) continue;
+        const double* v = s[cc];
+        double r = (kh == 0 ? v[0] : 0.0) + (kh == 2 ? v[1] : 0.0) + (kw == 0 ? v[2] : 0.0) + (kw == 2 ? v[3] : 0.0);
+        if (kh == 0 && kw == 0) r -= v[4];
+        if (kh == 0 && kw == 2) r -= v[5];
+        if (kh == 2 && kw == 0) r -= v[6];
+        if (kh == 2 && kw == 2) r -= v[7];
+        u[(int64_t)(blockIdx.x * 32 + cc) * 9 + tap] = (float)r;
     }
 }
 
@@ -526,6 +595,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
             const float4 b = *reinterpret_cast<const float4*>(s + (int64_t)k * slab_stride);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
+        if (ep.corr_u) {       // fp32 conv weight gradient: what the padding taps accumulated through the BatchNorm shift
+            const int tap = col / ep.corr_C, ci = col - tap * ep.corr_C;
+            const float u = ep.corr_u[row * 9 + tap];
+            const float4 shv = *reinterpret_cast<const float4*>(ep.corr_sh + ci);
+            a.x = fmaf(-shv.x, u, a.x); a.y = fmaf(-shv.y, u, a.y); a.z = fmaf(-shv.z, u, a.z); a.w = fmaf(-shv.w, u, a.w);
+        }
         float* o = ep.out + row * ep.ld + col;
         o[0] = epi_apply(ep, a.x, row, col);
         o[1] = epi_apply(ep, a.y, row, col + 1);
@@ -555,6 +630,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* sl
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         a.x = row16_sum(a.x); a.y = row16_sum(a.y); a.z = row16_sum(a.z); a.w = row16_sum(a.w);
+        if (ep.corr_u) {       // as in splitk_reduce_kernel
+            const int tap = col / ep.corr_C, ci = col - tap * ep.corr_C;
+            const float u = ep.corr_u[row * 9 + tap];
+            const float4 shv = *reinterpret_cast<const float4*>(ep.corr_sh + ci);
+            a.x = fmaf(-shv.x, u, a.x); a.y = fmaf(-shv.y, u, a.y); a.z = fmaf(-shv.z, u, a.z); a.w = fmaf(-shv.w, u, a.w);
+        }
         if (ok && g == 0) {
             float* o = ep.out + row * ep.ld + col;
             o[0] = epi_apply(ep, a.x, row, col);
@@ -713,10 +794,13 @@ static int wgrad_splits(int64_t M, int Cin, int Cout) {
 }
 
 static size_t wgrad_codes_bytes(int64_t M) { return (size_t)((M + 31) / 32 * 32 + 255) / 256 * 256; }
+static size_t wgrad_border_bytes(int N, int Cout) {      // per-frame border sums (fp64) + U[Cout][9]
+    return ((size_t)N * 8 * Cout * sizeof(double) + 255) / 256 * 256 + ((size_t)Cout * 9 * sizeof(float) + 255) / 256 * 256;
+}
 
 size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     const int64_t M = (int64_t)N * H * W;
-    return wgrad_codes_bytes(M) + (size_t)wgrad_splits(M, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
+    return wgrad_codes_bytes(M) + wgrad_border_bytes(N, Cout) + (size_t)wgrad_splits(M, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
 }
 
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
@@ -734,14 +818,22 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     const int nsplit = wgrad_splits(M, Cin, Cout);
     const int ktiles = (int)((M + BK - 1) / BK);
     const int64_t slab = (int64_t)Cout * 9 * Cin;
-    uint8_t* codes = (uint8_t*)ws;
-    float* slabs = (float*)((char*)ws + wgrad_codes_bytes(M));
+    uint32_t* codes = (uint32_t*)ws;
+    double* bparts = (double*)((char*)ws + wgrad_codes_bytes(M));
+    float* bu = (float*)((char*)bparts + ((size_t)N * 8 * Cout * sizeof(double) + 255) / 256 * 256);
+    float* slabs = (float*)((char*)ws + wgrad_codes_bytes(M) + wgrad_border_bytes(N, Cout));
     {
         const int Mpad = (int)((M + 31) / 32 * 32);
-        int blocks = (Mpad + 255) / 256;
+        int blocks = (Mpad / 4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(border_codes_kernel, dim3(blocks), dim3(256), 0, st, codes, (int)M, Mpad, H, W);
         GN_LAUNCH_CHECK("conv3x3_wgrad.codes");
+    }
+    if (scale) {
+        hipLaunchKernelGGL(wgrad_border_sums_kernel, dim3(N), dim3(256), 0, st, dy, bparts, H, W, Cout);
+        GN_LAUNCH_CHECK("conv3x3_wgrad.border_sums");
+        hipLaunchKernelGGL(wgrad_border_u_kernel, dim3((Cout + 31) / 32), dim3(256), 0, st, bparts, N, Cout, bu);
+        GN_LAUNCH_CHECK("conv3x3_wgrad.border_u");
     }
     MCLoader<false>::P ap{dy, Cout, Cout, (int)M, nullptr, nullptr, 1};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
@@ -755,6 +847,7 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     }
     if (rc) return rc;
     EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    if (scale) { er.corr_u = bu; er.corr_sh = shift; er.corr_C = Cin; }
     return launch_splitk_reduce("conv3x3_wgrad.reduce", slabs, nsplit, slab, er, st);
 }
 

@@ -106,6 +106,20 @@ def pool_case(name, hc, wc, c):
     t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dzb, p, idx, coef3, None, dyp, dparts, n, hc, wc, c))
     gb = (dz.numel() * 2 + p.numel() * 5 + y.numel() * 2) / 1e9
     print(f"{name} bnpool bwd (bf16 dz, bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    # the 16-bit step's own variants: 16-bit conv output -> 16-bit pooled activation; 16-bit dz and p -> 16-bit padded dy
+    yb = y.to(torch.bfloat16); pb = torch.empty(n, hp, wp, c, dtype=torch.bfloat16, device=dev)
+    t, ta = timeit(lambda: ops.pool_bnstats_fwd(yb, pb, idx, partials, n, hc, wc, c))
+    gb = (y.numel() * 2 + p.numel() * 3) / 1e9
+    print(f"{name} pool fwd (bf16 y -> bf16 p): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    t, ta = timeit(lambda: ops.bnpool_bwd_bf16p(dzb, pb, idx, coef3, None, dyp, dparts, n, hc, wc, c))
+    gb = (dz.numel() * 2 + p.numel() * 3 + y.numel() * 2) / 1e9
+    print(f"{name} bnpool bwd (bf16 dz, bf16 p, bf16 padded dy): {t:8.3f} ms  {gb / t * 1e3:7.0f} GB/s")
+    mean = torch.randn(c, device=dev); invstd = torch.rand(c, device=dev) + 0.5
+    rparts = torch.empty(ops.stat_parts(n * hp * wp // 64) * 2 * c, dtype=torch.float64, device=dev)
+    t, ta = timeit(lambda: ops.bn_bwd_reduce(dz, p, mean, invstd, rparts, n * hp * wp, c))
+    print(f"{name} bn_bwd_reduce fp32: {t:8.3f} ms  {dz.numel() * 8 / 1e9 / t * 1e3:7.0f} GB/s")
+    t, ta = timeit(lambda: ops.bn_bwd_reduce(dzb, pb, mean, invstd, rparts, n * hp * wp, c))
+    print(f"{name} bn_bwd_reduce bf16: {t:8.3f} ms  {dz.numel() * 4 / 1e9 / t * 1e3:7.0f} GB/s")
 
 
 if len(sys.argv) > 2 and sys.argv[2] == "pool":
