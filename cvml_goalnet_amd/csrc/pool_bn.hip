@@ -11,7 +11,6 @@
 // ATen's CPU implementation (which accumulates float statistics in double).
 #include <hip/hip_bf16.h>
 #include <stdlib.h>
-#include <type_traits>
 
 #include "common.h"
 
@@ -298,25 +297,6 @@ __device__ __forceinline__ void slice_reduce_store(double (&v)[2][4], int nv, in
     }
 }
 
-template <int LP>
-__device__ __forceinline__ void slice_reduce_store_lp(double (&v)[2][4], int nv, int tid, double* red, double* out0, double* out1) {
-    // threads with the same tid % LP own the same 4 channels; 256 / LP such threads per block
-    __syncthreads();
-    for (int a = 0; a < nv; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[(a * 256 + tid) * 4 + c] = v[a][c];
-    __syncthreads();
-    if (tid < LP) {
-        for (int a = 0; a < nv; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double s = 0.0;
-                for (int t = tid; t < 256; t += LP) s += red[(a * 256 + t) * 4 + c];
-                (a == 0 ? out0 : out1)[tid * 4 + c] = s;
-            }
-    }
-}
-
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
     return (unsigned)(*reinterpret_cast<const unsigned short*>(&x)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&y)) << 16);
@@ -427,174 +407,6 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const YT* __re
     }
     double* row = partials + (int64_t)slot * 2 * C + (blockIdx.x % ccn) * CS;
     slice_reduce_store(acc, 2, tid, reinterpret_cast<double*>(smem), row, row + C);
-}
-
-// v4 forward. Counters and the ISA of v2 showed a kernel bound by instruction issue and occupancy, not by HBM: ~460 vector +
-// ~560 scalar instructions per block row (nine LDS reads and eight compare-and-select steps per output, 64-bit index
-// arithmetic per pass), two barriers per row and one row of loads in flight. v4:
-//  * the 3 x 3 maximum is separable. A thread owns ONE pooled column for the whole unit (the block is as wide as the row:
-//    8 lanes x ceil8(Wc) pixels, up to 1024 threads), so for each arriving conv row it computes that row's 3-wide maximum
-//    (value + kw of its first maximum) once, from its own pixel (registers) and two neighbours (LDS), and keeps the row
-//    maxima of the two rows above in registers; the window result is the merge of the three row maxima in kh order. The
-//    scan-order tie rule survives: the first maximum in (kh, kw) order lies in the first row that holds the maximum, at
-//    that row's first maximal kw, and "NaN wins, the last NaN stays" composes the same way. Two LDS reads and four compare
-//    steps per output, one barrier per row (the raw rows alternate between two LDS buffers);
-//  * the three row-maximum register sets and the three prefetch registers take their roles in turn (row loop unrolled by
-//    three): no moves, and three conv rows of loads in flight per thread;
-//  * every address is a uniform row pointer (scalar adds per row) + a loop-invariant 32-bit lane offset;
-//  * EXACT = ATen's comparison `v > best || isnan(v)`; the plain `v > best` is the same function on NaN-free windows and
-//    costs 3 vector + 0 scalar instructions per step instead of 4 + 1: a block-wide flag, raised by the first conv row of
-//    the unit that holds a NaN (detector: the sum of the loaded values, so +inf next to -inf raises it too), switches that
-//    and all later rows of the unit to the exact form.
-//  * vmcnt counts loads and stores together, in order, and hipcc can only count what is issued unconditionally: every load, LDS
-//    write and store of the row loop is unconditional. Threads past the end of the row work on clamped columns (their loads,
-//    LDS writes and stores repeat a neighbour's, with identical values); the first two rows of a unit (no output yet) and
-//    the last one or two (partial triple) are peeled out of the unrolled loop; the argmax store is a template flag.
-template <typename YT, typename PT, int NPW, bool HAS_IDX>
-__global__ __launch_bounds__(1024) void pool_bnstats_fwd_v4_kernel(const YT* __restrict__ y, PT* __restrict__ p,
-                                                                  uint8_t* __restrict__ idx, double* __restrict__ partials,
-                                                                  int N, int Hc, int Wc, int C, int bands) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][Wc][CS] floats, the NaN flag; reused by the reduction
-    const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
-    const int PPP = (int)blockDim.x >> 3;            // pixels per pass
-    const int ccn = C / CS;
-    const int slot = blockIdx.x / ccn, c0 = (blockIdx.x % ccn) * CS + l8 * 4;
-    const int Hp = Hc - 2, Wp = Wc - 2;
-    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    uint32_t yoff[NPW], poff[NPW], ioff[NPW], lwr[NPW], lrd[NPW];
-    bool valid[NPW];
-#pragma unroll
-    for (int ps = 0; ps < NPW; ++ps) {
-        const int x = px + PPP * ps, xc = x < Wc ? x : Wc - 1, xp = x < Wp ? x : Wp - 1;
-        valid[ps] = x < Wp;
-        yoff[ps] = (uint32_t)(((int64_t)xc * C + c0) * (int64_t)sizeof(YT));
-        poff[ps] = (uint32_t)(((int64_t)xp * C + c0) * (int64_t)sizeof(PT));
-        ioff[ps] = (uint32_t)(xp * CS + l8 * 4);
-        lwr[ps] = (uint32_t)((xc * CS + l8 * 4) * 4);              // where this thread's loaded pixel goes in a row buffer
-        lrd[ps] = (uint32_t)((xp * CS + l8 * 4) * 4);              // first pixel of the window this thread computes
-    }
-    struct RowMax { float4 v[NPW]; unsigned k[NPW][4]; };            // a conv row's 3-wide maxima at this thread's columns + their kw
-    typedef decltype(load_dz4_raw(y)) RawT;
-    struct RawRow { RawT q[NPW]; };
-    int* nanflag = reinterpret_cast<int*>(smem + (size_t)2 * Wc * CS);
-    for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {
-        const int n = unit / bands, band = unit % bands;
-        const int p0 = (int)((int64_t)Hp * band / bands), p1 = (int)((int64_t)Hp * (band + 1) / bands);
-        const char* yrow = reinterpret_cast<const char*>(y + ((int64_t)n * Hc + p0) * Wc * C);          // conv row being fetched
-        char* prow = reinterpret_cast<char*>(p + ((int64_t)n * Hp + p0) * Wp * C);                      // pooled row being written
-        char* irow = HAS_IDX ? reinterpret_cast<char*>(idx + (((int64_t)n * ccn + blockIdx.x % ccn) * Hp + p0) * Wp * CS) : nullptr;
-        const int64_t ystep = (int64_t)Wc * C * sizeof(YT), pstep = (int64_t)Wp * C * sizeof(PT), istep = (int64_t)Wp * CS;
-        int fr = p0;                                                   // the conv row yrow points at
-        auto fetch = [&](RawRow& ry) {       // past the frame's last row that row is fetched again, never consumed
-#pragma unroll
-            for (int ps = 0; ps < NPW; ++ps) ry.q[ps] = load_dz4_raw(reinterpret_cast<const YT*>(yrow + yoff[ps]));
-            if (fr + 1 < Hc) { yrow += ystep; ++fr; }
-        };
-        auto step = [&](auto outc, int r, const RowMax& m2, const RowMax& m1, RowMax& cur, RawRow& ry) {
-            constexpr bool OUT = decltype(outc)::value;
-            char* buf = reinterpret_cast<char*>(smem) + (size_t)(r & 1) * Wc * CS * 4;
-            float nansum = 0.f;
-#pragma unroll
-            for (int ps = 0; ps < NPW; ++ps) {
-                const float4 own = dz4_of(ry.q[ps]);
-                nansum += (own.x + own.y) + (own.z + own.w);
-                *reinterpret_cast<float4*>(buf + lwr[ps]) = own;
-            }
-            if (nansum != nansum) *nanflag = 1;
-            fetch(ry);                   // row r + 3 into the registers row r just left
-            __syncthreads();             // row r is complete in buf; buffer (r+1)&1 was last read in iteration r-1, which every
-                                         // wave finished before it arrived here
-            const bool exact = __builtin_amdgcn_readfirstlane(*nanflag) != 0;
-            auto windows = [&](auto ex) {
-                constexpr bool EXACT = decltype(ex)::value;
-                auto gt = [](float v, float b) { return EXACT ? (v > b || v != v) : v > b; };
-#pragma unroll
-                for (int ps = 0; ps < NPW; ++ps) {
-                    float4 c = *reinterpret_cast<const float4*>(buf + lrd[ps]);
-                    const float4 v1 = *reinterpret_cast<const float4*>(buf + lrd[ps] + CS * 4);
-                    const float4 v2 = *reinterpret_cast<const float4*>(buf + lrd[ps] + 2 * CS * 4);
-                    unsigned kc[4] = {0, 0, 0, 0};
-                    if (gt(v1.x, c.x)) { c.x = v1.x; kc[0] = 1; }
-                    if (gt(v1.y, c.y)) { c.y = v1.y; kc[1] = 1; }
-                    if (gt(v1.z, c.z)) { c.z = v1.z; kc[2] = 1; }
-                    if (gt(v1.w, c.w)) { c.w = v1.w; kc[3] = 1; }
-                    if (gt(v2.x, c.x)) { c.x = v2.x; kc[0] = 2; }
-                    if (gt(v2.y, c.y)) { c.y = v2.y; kc[1] = 2; }
-                    if (gt(v2.z, c.z)) { c.z = v2.z; kc[2] = 2; }
-                    if (gt(v2.w, c.w)) { c.w = v2.w; kc[3] = 2; }
-                    cur.v[ps] = c;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cur.k[ps][q] = kc[q];
-                    if (OUT) {
-                        float4 best = m2.v[ps];
-                        unsigned bi[4] = {m2.k[ps][0], m2.k[ps][1], m2.k[ps][2], m2.k[ps][3]};
-                        const float4 a = m1.v[ps];
-                        if (gt(a.x, best.x)) { best.x = a.x; bi[0] = 3 + m1.k[ps][0]; }
-                        if (gt(a.y, best.y)) { best.y = a.y; bi[1] = 3 + m1.k[ps][1]; }
-                        if (gt(a.z, best.z)) { best.z = a.z; bi[2] = 3 + m1.k[ps][2]; }
-                        if (gt(a.w, best.w)) { best.w = a.w; bi[3] = 3 + m1.k[ps][3]; }
-                        if (gt(c.x, best.x)) { best.x = c.x; bi[0] = 6 + kc[0]; }
-                        if (gt(c.y, best.y)) { best.y = c.y; bi[1] = 6 + kc[1]; }
-                        if (gt(c.z, best.z)) { best.z = c.z; bi[2] = 6 + kc[2]; }
-                        if (gt(c.w, best.w)) { best.w = c.w; bi[3] = 6 + kc[3]; }
-                        best = store_p4(reinterpret_cast<PT*>(prow + poff[ps]), best);
-                        if (HAS_IDX) *reinterpret_cast<uint32_t*>(irow + ioff[ps]) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-                        if (valid[ps]) {
-                            acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
-                            acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
-                            acc[0][2] += (double)best.z; acc[1][2] += (double)best.z * (double)best.z;
-                            acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
-                        }
-                    }
-                }
-            };
-            if (exact) windows(std::true_type{}); else windows(std::false_type{});
-            if (OUT) { prow += pstep; if (HAS_IDX) irow += istep; }
-        };
-        RowMax ra, rb, rc;
-        RawRow ya, yb, yc;
-        __syncthreads();                 // the previous unit's last reads of both row buffers and of its NaN flag
-        if (tid == 0) *nanflag = 0;
-        fetch(ya); fetch(yb); fetch(yc);
-        __syncthreads();
-        constexpr std::false_type NOOUT{};
-        constexpr std::true_type WOUT{};
-        step(NOOUT, p0, ra, ra, ra, ya);                 // rows p0, p0 + 1: row maxima only (the m2 / m1 arguments are not read)
-        step(NOOUT, p0 + 1, rb, rb, rb, yb);
-        int r = p0 + 2;
-        const int rend = p1 + 2;
-        for (; r + 3 <= rend; r += 3) {
-            step(WOUT, r, ra, rb, rc, yc);
-            step(WOUT, r + 1, rb, rc, ra, ya);
-            step(WOUT, r + 2, rc, ra, rb, yb);
-        }
-        if (r < rend) step(WOUT, r, ra, rb, rc, yc);
-        if (r + 1 < rend) step(WOUT, r + 1, rb, rc, ra, ya);
-    }
-    // per-channel sums over the block: lanes l8, l8 + 8, ... of a wave (xor-shuffles over the pixel bits), then the waves in order
-    __syncthreads();
-    double* red = reinterpret_cast<double*>(smem);                    // [waves][2][8 lanes][4]
-    const int wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double v = acc[a][c];
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if ((tid & 63) < 8) red[((wave * 2 + a) * 8 + l8) * 4 + c] = v;
-        }
-    __syncthreads();
-    if (tid < 8) {
-        double* row = partials + (int64_t)slot * 2 * C + (blockIdx.x % ccn) * CS;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double t = 0.0;
-                for (int w = 0; w < nwaves; ++w) t += red[((w * 2 + a) * 8 + tid) * 4 + c];
-                row[a * C + tid * 4 + c] = t;
-            }
-    }
 }
 
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
@@ -732,22 +544,7 @@ template <typename YT, typename PT>
 static void launch_pool_fwd_v2(int nparts, size_t lds, hipStream_t st, const YT* y, PT* p, uint8_t* idx, double* partials, int N, int Hc, int Wc, int C) {
     const dim3 grid(nparts * (C / CS)), block(256);
     const int bands = row_bands(nparts, N, Hc - 2);
-    static const bool v2 = getenv("GOALNET_POOL_V4") == nullptr;       // v4 (separable maximum) is opt-in until it beats v2
-    if (!v2) {
-        // one pixel per thread up to 128-pixel rows (1024 threads), two beyond; whole waves (8 pixels x 8 lanes)
-        const int npw = Wc <= 128 ? 1 : Wc <= 256 ? 2 : 3;
-        const int ppp = ((Wc + npw - 1) / npw + 7) / 8 * 8;
-        size_t l4 = (size_t)2 * Wc * CS * sizeof(float) + 16;          // two row buffers + the NaN flag
-        const size_t lred = (size_t)(ppp / 8) * 64 * sizeof(double);   // [waves][2][8][4] doubles of the final reduction
-        if (l4 < lred) l4 = lred;
-        const dim3 b4(ppp * 8);
-#define GN_POOL4(NPWV) do { if (idx) hipLaunchKernelGGL((pool_bnstats_fwd_v4_kernel<YT, PT, NPWV, true>), grid, b4, l4, st, y, p, idx, partials, N, Hc, Wc, C, bands); \
-                           else hipLaunchKernelGGL((pool_bnstats_fwd_v4_kernel<YT, PT, NPWV, false>), grid, b4, l4, st, y, p, idx, partials, N, Hc, Wc, C, bands); } while (0)
-        switch (npw) { case 1: GN_POOL4(1); break; case 2: GN_POOL4(2); break; default: GN_POOL4(3); break; }
-#undef GN_POOL4
-        return;
-    }
-    switch ((Wc + 31) / 32) {
+    switch ((Wc + 31) / 32) {                                    // passes of 32 pixels per conv row; the LDS limit keeps Wc <= 170
     case 1: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 1>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
     case 2: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 2>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
     case 3: hipLaunchKernelGGL((pool_bnstats_fwd_v2_kernel<YT, PT, 3>), grid, block, lds, st, y, p, idx, partials, N, Hc, Wc, C, bands); break;
