@@ -263,7 +263,9 @@ struct ConvALoader {
 // border pixels of a frame, so nothing cancels: the correction is ~5 % of the accumulated magnitude.
 // codes4[kt * 8 + k0] packs the codes of the four pixels kt * 32 + k0 + 8 i one thread loads of a K-tile; the word for the
 // next K-tile is fetched one K-tile ahead.
-template <bool AFFINE>
+// DSEL (few frames: the reference's 10-frame sub-batches, where two more launches for U cost more than the GEMM loses): the
+// first version's data select instead — every tap loads, finish() zeroes the padding taps after the affine, no correction.
+template <bool AFFINE, bool DSEL = false>
 struct ConvWgradBLoader {
     struct P {
         const float* x; int H, W, C; int M;
@@ -274,7 +276,7 @@ struct ConvWgradBLoader {
     const float* x;
     __amdgpu_buffer_rsrc_t rcodes;
     int W, C, M, k0, tapshift, nextkt;
-    unsigned voff[4], bad4, nextcode;
+    unsigned voff[4], bad4, nextcode, badnow;
     float4 sc, sh;
     __device__ ConvWgradBLoader(const P& p, int col0, int tid) {
         const int col = col0 + (tid & 31) * 4;
@@ -299,7 +301,9 @@ struct ConvWgradBLoader {
     }
     __device__ __forceinline__ void issue(int kt, float4 (&r)[4]) {
         const int mbase = kt * BK;
-        const unsigned bad = (nextkt == kt ? nextcode : load_code(kt)) & bad4;      // pixels >= M carry 0xF: every tap bad
+        const unsigned badc = (nextkt == kt ? nextcode : load_code(kt)) & bad4;     // pixels >= M carry 0xF: every tap bad
+        badnow = badc;
+        const unsigned bad = DSEL ? 0u : badc;
         // pixels [mbase - (W+1), mbase + 32 + (W+1)) clipped to the tensor: taps past the end are out of range (0)
         const int64_t lead = (int64_t)mbase - (W + 1);
         const int64_t last = (int64_t)mbase + BK + (W + 1) < M ? (int64_t)mbase + BK + (W + 1) : M;
@@ -316,7 +320,10 @@ struct ConvWgradBLoader {
         nextkt = kt + 1;
     }
     __device__ __forceinline__ void finish(float4 (&r)[4]) const {
-        if (AFFINE) {
+        if (DSEL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = f4sel(((badnow >> (8 * i)) & 0xFFu) == 0, AFFINE ? f4fma(r[i], sc, sh) : r[i]);
+        } else if (AFFINE) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = f4fma(r[i], sc, sh);
         }
@@ -360,6 +367,17 @@ __global__ __launch_bounds__(256) void wgrad_border_sums_kernel(const float* __r
     }
 }
 
+// U[co][tap] of the pixels where `tap` falls into the padding, from the eight border sums v[0..7] of channel co
+__device__ __forceinline__ float border_u_of(const double* v, int tap) {
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    double r = (kh == 0 ? v[0] : 0.0) + (kh == 2 ? v[1] : 0.0) + (kw == 0 ? v[2] : 0.0) + (kw == 2 ? v[3] : 0.0);
+    if (kh == 0 && kw == 0) r -= v[4];
+    if (kh == 0 && kw == 2) r -= v[5];
+    if (kh == 2 && kw == 0) r -= v[6];
+    if (kh == 2 && kw == 2) r -= v[7];
+    return (float)r;
+}
+
 __global__ __launch_bounds__(256) void wgrad_border_u_kernel(const double* __restrict__ parts, int N, int Cout, float* __restrict__ u) {
     __shared__ double s[32][8];
     const int cl = threadIdx.x & 31, j = threadIdx.x >> 5;
@@ -377,15 +395,8 @@ __global__ __launch_bounds__(256) void wgrad_border_u_kernel(const double* __res
     s[cl][j] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     for (int t = threadIdx.x; t < 32 * 9; t += 256) {
-        const int cc = t / 9, tap = t - 9 * cc, kh = tap / 3, kw = tap - 3 * kh;
-        if (blockIdx.x * 32 + cc >= Cout) continue;
-        const double* v = s[cc];
-        double r = (kh == 0 ? v[0] : 0.0) + (kh == 2 ? v[1] : 0.0) + (kw == 0 ? v[2] : 0.0) + (kw == 2 ? v[3] : 0.0);
-        if (kh == 0 && kw == 0) r -= v[4];
-        if (kh == 0 && kw == 2) r -= v[5];
-        if (kh == 2 && kw == 0) r -= v[6];
-        if (kh == 2 && kw == 2) r -= v[7];
-        u[(int64_t)(blockIdx.x * 32 + cc) * 9 + tap] = (float)r;
+        const int cc = t / 9, tap = t - 9 * cc;
+        if (blockIdx.x * 32 + cc < Cout) u[(int64_t)(blockIdx.x * 32 + cc) * 9 + tap] = border_u_of(s[cc], tap);
     }
 }
 
@@ -822,6 +833,7 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     double* bparts = (double*)((char*)ws + wgrad_codes_bytes(M));
     float* bu = (float*)((char*)bparts + ((size_t)N * 8 * Cout * sizeof(double) + 255) / 256 * 256);
     float* slabs = (float*)((char*)ws + wgrad_codes_bytes(M) + wgrad_border_bytes(N, Cout));
+    const bool dsel = (int64_t)N * (H > W ? H : W) <= 4096;      // few frames: data select in the loop, no correction pass
     {
         const int Mpad = (int)((M + 31) / 32 * 32);
         int blocks = (Mpad / 4 + 255) / 256;
@@ -829,7 +841,7 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
         hipLaunchKernelGGL(border_codes_kernel, dim3(blocks), dim3(256), 0, st, codes, (int)M, Mpad, H, W);
         GN_LAUNCH_CHECK("conv3x3_wgrad.codes");
     }
-    if (scale) {
+    if (scale && !dsel) {
         hipLaunchKernelGGL(wgrad_border_sums_kernel, dim3(N), dim3(256), 0, st, dy, bparts, H, W, Cout);
         GN_LAUNCH_CHECK("conv3x3_wgrad.border_sums");
         hipLaunchKernelGGL(wgrad_border_u_kernel, dim3((Cout + 31) / 32), dim3(256), 0, st, bparts, N, Cout, bu);
@@ -838,7 +850,10 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     MCLoader<false>::P ap{dy, Cout, Cout, (int)M, nullptr, nullptr, 1};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
     int rc;
-    if (scale) {
+    if (scale && dsel) {
+        ConvWgradBLoader<true, true>::P bp{x, H, W, Cin, (int)M, scale, shift, codes};
+        rc = launch_gemm<MCLoader<false>, ConvWgradBLoader<true, true>>("conv3x3_wgrad", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
+    } else if (scale) {
         ConvWgradBLoader<true>::P bp{x, H, W, Cin, (int)M, scale, shift, codes};
         rc = launch_gemm<MCLoader<false>, ConvWgradBLoader<true>>("conv3x3_wgrad", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
     } else {
@@ -847,7 +862,7 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     }
     if (rc) return rc;
     EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
-    if (scale) { er.corr_u = bu; er.corr_sh = shift; er.corr_C = Cin; }
+    if (scale && !dsel) { er.corr_u = bu; er.corr_sh = shift; er.corr_C = Cin; }
     return launch_splitk_reduce("conv3x3_wgrad.reduce", slabs, nsplit, slab, er, st);
 }
 
