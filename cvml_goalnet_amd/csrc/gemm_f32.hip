@@ -833,7 +833,9 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     double* bparts = (double*)((char*)ws + wgrad_codes_bytes(M));
     float* bu = (float*)((char*)bparts + ((size_t)N * 8 * Cout * sizeof(double) + 255) / 256 * 256);
     float* slabs = (float*)((char*)ws + wgrad_codes_bytes(M) + wgrad_border_bytes(N, Cout));
-    const bool dsel = (int64_t)N * (H > W ? H : W) <= 4096;      // few frames: data select in the loop, no correction pass
+    // few frames: data select in the loop, no correction pass (GOALNET_WGRAD_PATH=select|correct forces one: tests, A/B runs)
+    const char* force = getenv("GOALNET_WGRAD_PATH");
+    const bool dsel = force && force[0] == 's' ? true : force && force[0] == 'c' ? false : (int64_t)N * (H > W ? H : W) <= 4096;
     {
         const int Mpad = (int)((M + 31) / 32 * 32);
         int blocks = (Mpad / 4 + 255) / 256;

@@ -126,6 +126,7 @@ def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
     close(f"conv3x3_fwd[{n}x{h}x{w}x{cin}->{cout}]", y, nhwc(ref), rtol=5e-6)   # K up to 4608 fp32 accumulations
 
 
+@pytest.mark.parametrize("path", ["select", "correct"])
 @pytest.mark.parametrize("n,h,w,cin,cout,affine", [
     (2, 7, 5, 64, 256, True),
     (3, 13, 13, 64, 256, True),
@@ -134,8 +135,14 @@ def test_conv3x3_fwd(n, h, w, cin, cout, affine, bias, relu):
     (16, 11, 11, 256, 512, True),     # M = 1936 -> 3 splits over the reduction
     (16, 13, 13, 64, 256, True),      # M = 2704 -> 5 splits, 576 columns (4.5 N-tiles)
     (40, 13, 13, 64, 256, False),
+    (2, 1, 9, 64, 128, True),         # one image row: first and last row coincide (every kh != 1 tap is padding)
+    (3, 4, 1, 64, 128, True),         # one image column
+    (1, 1, 1, 64, 128, True),
 ])
-def test_conv3x3_wgrad(n, h, w, cin, cout, affine):
+def test_conv3x3_wgrad(n, h, w, cin, cout, affine, path, monkeypatch):
+    # "select": padding taps zeroed in the loop (few frames); "correct": padding taps load zeros, the BatchNorm shift they pick up
+    # is subtracted in the slab reduction from border sums of dy (the bench-size path, forced here onto small shapes)
+    monkeypatch.setenv("GOALNET_WGRAD_PATH", path)
     x = rnd(n, h, w, cin, seed=12)
     sc = rnd(cin, seed=13, lo=0.5, hi=1.5) if affine else None
     sh = rnd(cin, seed=14, lo=-0.5, hi=0.5) if affine else None
