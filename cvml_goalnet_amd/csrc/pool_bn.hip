@@ -409,6 +409,188 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_v2_kernel(const YT* __re
     slice_reduce_store(acc, 2, tid, reinterpret_cast<double*>(smem), row, row + C);
 }
 
+// ---- 16-bit conv output -> 16-bit pooled activation (the 16-bit modes' blocks 2 and 3): integer keys ----------------------------
+// v2 is bound by instruction issue, not by HBM (~38 vector instructions per channel-output: eight compare + select steps on
+// (value, index) pairs). For 16-bit inputs the window maximum AND its first position come out of one unsigned maximum over
+// 32-bit keys  (value bits << 16) | (8 - tap):  non-negative IEEE values (bf16 or fp16) order like their bit patterns, and
+// among equal values the smaller tap has the larger key — ATen's first-maximum rule. v_max3_u32 folds nine keys in four
+// instructions; building a key is one v_lshl_or / v_and_or. A key whose value field lies above +inf's pattern flags a NaN
+// or a negative value (sign bit set, -0.0 included) in the window: that thread recomputes its four channels with the exact
+// float comparisons of v2 (a ReLU output has neither, so this is the rare path). Same thread -> (pixel, channel) mapping,
+// same statistics order, same argmax layout as v2: every result, the fp64 partial rows included, is bit-identical to v2's.
+template <bool F16>
+__device__ __forceinline__ float h16_to_f32(unsigned v16) {
+    if (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)v16);
+    return __uint_as_float(v16 << 16);
+}
+
+// the exact window of one lane (4 channels): ATen's comparisons on the float values, as v2. in = (p words, argmax word, lane
+// flag): lanes whose windows were ordinary get their fast-path result back.
+// the exact window of two channels (one 32-bit word of a lane): ATen's comparisons on the float values, as v2. Returns
+// (value of channel 0 | value of channel 1 << 16, tap of channel 0 | tap of channel 1 << 8).
+template <bool F16>
+__device__ __attribute__((noinline)) uint2 pool_window_exact(const char* ring, unsigned o0, unsigned o1, unsigned o2, unsigned loff, unsigned pix_stride) {
+    float best[2]; unsigned raw[2], bi[2] = {0, 0};
+    for (int kh = 0; kh < 3; ++kh) {
+        const char* row = ring + (kh == 0 ? o0 : kh == 1 ? o1 : o2) + loff;
+        for (int kw = 0; kw < 3; ++kw) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(row + kw * pix_stride);
+            const unsigned r2[2] = {v & 0xffffu, v >> 16};
+            const unsigned k = kh * 3 + kw;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float f = h16_to_f32<F16>(r2[c]);
+                if (k == 0 || f > best[c] || f != f) { best[c] = f; raw[c] = r2[c]; bi[c] = k; }
+            }
+        }
+    }
+    return make_uint2(raw[0] | (raw[1] << 16), bi[0] | (bi[1] << 8));
+}
+
+// Addressing: v2 spends as many SCALAR instructions per row (~420: 64-bit index products per pass, `% 3` ring indices) as
+// vector ones, and the CU's four SIMDs share one scalar unit. Here every address is a uniform row pointer advanced by a scalar
+// add per row plus a loop-invariant 32-bit lane offset, and the three ring rows rotate as three scalar offsets.
+// With both instruction streams cut to a third the kernel is what is left: latency-bound — five resident blocks x one conv row
+// of loads in flight each. WPL = 32-bit words per lane: 2 (4 channels, 32-channel slices, 64 B per pixel) or 4 (8 channels,
+// 64-channel slices, 128 B per pixel: twice the bytes in flight per thread at about the same occupancy). The pixel -> thread
+// mapping, hence every per-channel summation order, is v2's in both.
+template <bool F16, int NPW, int WPL>
+__global__ __launch_bounds__(256) void pool_bnstats_fwd_k16_kernel(const unsigned short* __restrict__ y, unsigned short* __restrict__ p,
+                                                                  uint8_t* __restrict__ idx, double* __restrict__ partials,
+                                                                  int N, int Hc, int Wc, int C, int bands) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [3][Wc][CSL] 16-bit values; reused by the reduction
+    constexpr int CPL = 2 * WPL, CSL = 8 * CPL;                       // channels per lane, per block slice
+    typedef unsigned wvec __attribute__((ext_vector_type(WPL)));
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
+    const int ccn = C / CSL;
+    const int slot = blockIdx.x / ccn, c0 = (blockIdx.x % ccn) * CSL + l8 * CPL;
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    constexpr unsigned INF16 = F16 ? 0x7C00u : 0x7F80u;
+    constexpr unsigned PIX = CSL * 2;                                 // bytes per pixel in a ring row
+    const unsigned rowbytes = (unsigned)Wc * PIX;
+    double acc[2][CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[0][c] = acc[1][c] = 0.0;
+    uint32_t yoff[NPW], poff[NPW], ioff[NPW], loff[NPW];              // loop-invariant lane offsets (bytes)
+#pragma unroll
+    for (int ps = 0; ps < NPW; ++ps) {
+        const int x = px + 32 * ps, xc = x < Wc ? x : Wc - 1;
+        yoff[ps] = (uint32_t)(((int64_t)xc * C + c0) * 2);
+        poff[ps] = (uint32_t)(((int64_t)x * C + c0) * 2);
+        ioff[ps] = (uint32_t)(x * CS + (c0 % CS));                    // argmax bytes: 32-channel slices (idx_off)
+        loff[ps] = (uint32_t)(x * PIX + l8 * CPL * 2);
+    }
+    for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {
+        const int n = unit / bands, band = unit % bands;
+        const int p0 = (int)((int64_t)Hp * band / bands), p1 = (int)((int64_t)Hp * (band + 1) / bands);
+        const char* yrow = reinterpret_cast<const char*>(y + ((int64_t)n * Hc + p0) * Wc * C);          // conv row being fetched
+        char* prow = reinterpret_cast<char*>(p + ((int64_t)n * Hp + p0) * Wp * C);                      // pooled row being written
+        char* irow = idx ? reinterpret_cast<char*>(idx + (((int64_t)n * (C / CS) + c0 / CS) * Hp + p0) * Wp * CS) : nullptr;
+        const int64_t ystep = (int64_t)Wc * C * 2, pstep = (int64_t)Wp * C * 2, istep = (int64_t)Wp * CS;
+        int fr = p0;                                                   // the conv row yrow points at
+        wvec ry[NPW];
+        auto fetch = [&]() {       // unconditional loads; past the frame's last row that row is fetched again (never consumed)
+#pragma unroll
+            for (int ps = 0; ps < NPW; ++ps) ry[ps] = *reinterpret_cast<const wvec*>(yrow + yoff[ps]);
+            if (fr + 1 < Hc) { yrow += ystep; ++fr; }
+        };
+        auto stash = [&](unsigned ro) {
+#pragma unroll
+            for (int ps = 0; ps < NPW; ++ps)
+                if (px + 32 * ps < Wc) *reinterpret_cast<wvec*>(ring + ro + loff[ps]) = ry[ps];
+        };
+        unsigned o0 = 0, o1 = rowbytes, o2 = 2 * rowbytes;            // ring offsets of conv rows ph, ph + 1, ph + 2
+        __syncthreads();
+        fetch(); stash(o0);
+        fetch(); stash(o1);
+        fetch();
+        for (int ph = p0; ph < p1; ++ph) {
+            stash(o2);
+            fetch();
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < NPW; ++ps) {
+                if (px + 32 * ps < Wp) {
+                    unsigned key[CPL];                            // key[2 j] / key[2 j + 1]: low / high half of word j
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) key[c] = 0;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const char* row = ring + (kh == 0 ? o0 : kh == 1 ? o1 : o2) + loff[ps];
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const wvec v = *reinterpret_cast<const wvec*>(row + kw * PIX);
+                            const unsigned code = 8u - (unsigned)(kh * 3 + kw);
+#pragma unroll
+                            for (int j = 0; j < WPL; ++j) {
+                                key[2 * j] = max(key[2 * j], (v[j] << 16) | code);
+                                key[2 * j + 1] = max(key[2 * j + 1], (v[j] & 0xffff0000u) | code);
+                            }
+                        }
+                    }
+                    unsigned top = 0;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) top = max(top, key[c]);
+                    wvec pw16;                                     // pooled values, two per word
+                    unsigned taps[WPL];                            // their taps, one byte each (two per word)
+#pragma unroll
+                    for (int j = 0; j < WPL; ++j) {
+                        pw16[j] = (key[2 * j] >> 16) | (key[2 * j + 1] & 0xffff0000u);
+                        taps[j] = (8u - (key[2 * j] & 15u)) | ((8u - (key[2 * j + 1] & 15u)) << 8);
+                    }
+                    const bool special = (top >> 16) > INF16;
+                    if (__builtin_amdgcn_ballot_w64(special) != 0) {          // rare and wave-uniform: real calls, never if-converted
+#pragma unroll
+                        for (int j = 0; j < WPL; ++j) {
+                            const uint2 e = pool_window_exact<F16>(ring, o0, o1, o2, loff[ps] + 4 * j, PIX);
+                            if (special) { pw16[j] = e.x; taps[j] = e.y; }
+                        }
+                    }
+                    *reinterpret_cast<wvec*>(prow + poff[ps]) = pw16;
+                    if (irow) {
+                        if (WPL == 2) *reinterpret_cast<uint32_t*>(irow + ioff[ps]) = taps[0] | (taps[1] << 16);
+                        else *reinterpret_cast<uint2*>(irow + ioff[ps]) = make_uint2(taps[0] | (taps[1] << 16), taps[WPL - 2] | (taps[WPL - 1] << 16));
+                    }
+#pragma unroll
+                    for (int j = 0; j < WPL; ++j) {
+                        const float f0 = h16_to_f32<F16>(pw16[j] & 0xffffu), f1 = h16_to_f32<F16>(pw16[j] >> 16);
+                        acc[0][2 * j] += (double)f0; acc[1][2 * j] += (double)f0 * (double)f0;
+                        acc[0][2 * j + 1] += (double)f1; acc[1][2 * j + 1] += (double)f1 * (double)f1;
+                    }
+                }
+            }
+            prow += pstep;
+            if (irow) irow += istep;
+            const unsigned t = o0; o0 = o1; o1 = o2; o2 = t;
+            __syncthreads();
+        }
+    }
+    // per-channel sums over the block in v2's order: lane l8's channels over the pixel lanes px = 0 .. 31
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);                    // [2][256][CPL]
+    double* row = partials + (int64_t)slot * 2 * C + (blockIdx.x % ccn) * CSL;
+#pragma unroll
+    for (int h = 0; h < CPL / 4; ++h) {                               // 4 channels per round: 16 KB of scratch, as v2
+        if (h) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[(a * 256 + tid) * 4 + c] = acc[a][4 * h + c];
+        __syncthreads();
+        if (tid < 8) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double t = 0.0;
+                    for (int q = tid; q < 256; q += 8) t += red[(a * 256 + q) * 4 + c];
+                    row[a * C + tid * CPL + 4 * h + c] = t;
+                }
+        }
+    }
+}
+
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
 template <typename DZ, typename PT, int NP, bool F16>
 __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
@@ -554,6 +736,33 @@ static void launch_pool_fwd_v2(int nparts, size_t lds, hipStream_t st, const YT*
     }
 }
 
+template <bool F16, int WPL>
+static void launch_pool_fwd_k16_w(int nparts, hipStream_t st, const void* y, void* p, uint8_t* idx, double* partials, int N, int Hc, int Wc, int C) {
+    constexpr int CSL = 16 * WPL;
+    const dim3 grid(nparts * (C / CSL)), block(256);
+    const int bands = row_bands(nparts, N, Hc - 2);
+    size_t lds = (size_t)3 * Wc * CSL * 2;
+    if (lds < 16384) lds = 16384;                               // the fp64 block reduction reuses the buffer (256 x 8 doubles)
+    const unsigned short* yy = (const unsigned short*)y;
+    unsigned short* pp = (unsigned short*)p;
+    switch ((Wc + 31) / 32) {
+    case 1: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 1, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    case 2: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 2, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    case 3: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 3, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    case 4: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 4, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    case 5: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 5, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    default: hipLaunchKernelGGL((pool_bnstats_fwd_k16_kernel<F16, 6, WPL>), grid, block, lds, st, yy, pp, idx, partials, N, Hc, Wc, C, bands); break;
+    }
+}
+
+template <bool F16>
+static void launch_pool_fwd_k16(int nparts, hipStream_t st, const void* y, void* p, uint8_t* idx, double* partials, int N, int Hc, int Wc, int C) {
+    const char* w = getenv("GOALNET_POOL_K16_WPL");             // 2 | 4: A/B runs
+    const bool wide = C % 64 == 0 && (size_t)3 * Wc * 64 * 2 <= 64 * 1024 && !(w && w[0] == '2');
+    if (wide) launch_pool_fwd_k16_w<F16, 4>(nparts, st, y, p, idx, partials, N, Hc, Wc, C);
+    else launch_pool_fwd_k16_w<F16, 2>(nparts, st, y, p, idx, partials, N, Hc, Wc, C);
+}
+
 template <typename DZ, typename PT, bool F16 = false>
 static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const DZ* dz, const PT* p, const uint8_t* idx, const float* coef3,
                                  float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
@@ -612,7 +821,10 @@ int goalnet_pool_bnstats_fwd_p16(const void* y, int y_bf16, void* p_bf16, uint8_
     const size_t need = lds < 16384 ? 16384 : lds;
     typedef __hip_bfloat16 bf;
     typedef _Float16 hf;
-    if (f16) {
+    if (y_bf16 && !getenv("GOALNET_POOL_K16_OFF")) {          // 16-bit in, 16-bit out: the integer-key kernel (bit-identical to v2)
+        if (f16) launch_pool_fwd_k16<true>(nparts, (hipStream_t)stream, y, p_bf16, idx, partials, N, Hc, Wc, C);
+        else launch_pool_fwd_k16<false>(nparts, (hipStream_t)stream, y, p_bf16, idx, partials, N, Hc, Wc, C);
+    } else if (f16) {
         if (y_bf16) launch_pool_fwd_v2<hf, hf>(nparts, need, (hipStream_t)stream, (const hf*)y, (hf*)p_bf16, idx, partials, N, Hc, Wc, C);
         else launch_pool_fwd_v2<float, hf>(nparts, need, (hipStream_t)stream, (const float*)y, (hf*)p_bf16, idx, partials, N, Hc, Wc, C);
     } else if (y_bf16) launch_pool_fwd_v2<bf, bf>(nparts, need, (hipStream_t)stream, (const bf*)y, (bf*)p_bf16, idx, partials, N, Hc, Wc, C);

@@ -656,6 +656,45 @@ def test_batchnorm_backward_passes_with_bf16_gradient_input(n, hc, wc, c):
     assert out["b16"][4].abs().max().item() > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,hc,wc,c,kind", [(3, 13, 13, 256, "relu"), (2, 11, 11, 512, "signed"), (2, 9, 40, 64, "special"),
+                                            (1, 76, 74, 64, "relu"), (4, 3, 3, 32, "signed")])
+def test_integer_key_pool_is_bit_identical_to_the_compare_and_select_kernel(n, hc, wc, c, kind, dtype, monkeypatch):
+    """16-bit conv output -> 16-bit pooled activation: the integer-key kernel (max over (value << 16 | 8 - tap) words; windows
+    holding a negative value, -0.0 or a NaN take its exact path) against v2's float compare-and-select on the same input:
+    pooled values, argmax bytes and the fp64 partial rows must agree bit for bit."""
+    g = torch.Generator().manual_seed(321)
+    y = torch.rand(n, hc, wc, c, generator=g) - 0.4
+    if kind == "relu":
+        y = F.relu(y)                                   # many exact zeros: ties everywhere, the fast path only
+    elif kind == "special":
+        y = F.relu(y)
+        flat = y.view(-1)
+        pick = torch.randperm(flat.numel(), generator=g)[:600]
+        flat[pick[:150]] = float("nan"); flat[pick[150:300]] = float("inf"); flat[pick[300:450]] = -0.0; flat[pick[450:]] = -float("inf")
+    yb = y.to(dtype).to(DEV)
+    hp, wp = hc - 2, wc - 2
+    parts = ops.stat_parts(8 * n)
+    out = {}
+    for name, off in (("v2", "1"), ("k16", None)):
+        if off:
+            monkeypatch.setenv("GOALNET_POOL_K16_OFF", off)
+        else:
+            monkeypatch.delenv("GOALNET_POOL_K16_OFF", raising=False)
+        p = torch.empty(n, hp, wp, c, dtype=dtype, device=DEV); idx = torch.empty(n, hp, wp, c, dtype=torch.uint8, device=DEV)
+        st = torch.empty(parts * 2 * c, dtype=torch.float64, device=DEV)
+        ops.pool_bnstats_fwd(yb, p, idx, st, n, hc, wc, c)
+        out[name] = (p.view(torch.int16).clone(), idx.clone(), st.view(torch.int64).clone())
+    assert torch.equal(out["v2"][1], out["k16"][1]), "argmax bytes differ"
+    pv, pk = out["v2"][0], out["k16"][0]
+    if kind == "special":                               # v2 re-rounds a NaN through float (canonical payload); compare NaN-ness there
+        fv, fk = pv.view(dtype).float(), pk.view(dtype).float()
+        assert torch.equal(torch.isnan(fv), torch.isnan(fk)) and torch.equal(pv[~torch.isnan(fv)], pk[~torch.isnan(fk)])
+    else:
+        assert torch.equal(pv, pk), "pooled values differ"
+        assert torch.equal(out["v2"][2], out["k16"][2]), "fp64 partial rows differ"
+
+
 @pytest.mark.parametrize("n,hc,wc,c", [(3, 9, 11, 64), (2, 13, 13, 256), (2, 40, 37, 32)])
 def test_bf16_pooled_activation_variants_match_the_fp32_kernels_on_the_stored_values(n, hc, wc, c):
     """precision="bf16" stores the pooled activation p of blocks 2 and 3 as bf16. The p16 pool kernel must store exactly
