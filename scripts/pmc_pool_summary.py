@@ -3,7 +3,7 @@
 import csv, glob, os, collections, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_a", "pmc_b"):
+for d in ("pmc_a", "pmc_b", "pmc_c"):
     fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "*", "*counter_collection.csv")), key=os.path.getmtime)
     if not fs:
         continue
