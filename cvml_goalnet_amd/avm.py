@@ -491,9 +491,9 @@ class AVM(nn.Module):
 
     @staticmethod
     def _bwd16_ok(wc):
-        """widths goalnet_bnpool_bwd_bf16p(_t) serves: three pooled rows of a 32-channel slice (value + argmax byte) in 64 KB
-        of LDS, i.e. conv outputs up to 138 pixels wide (frames up to ~416 px); wider blocks take the fp32 kernels"""
-        return 3 * (wc - 2) * 32 * 5 <= 65536
+        """widths goalnet_bnpool_bwd_bf16p(_t) serves: three ring rows (pooled row + 4 guard pixels) of a 32-channel slice (value +
+        argmax byte) in 64 KB of LDS, i.e. conv outputs up to 134 pixels wide (frames up to ~404 px); wider blocks take the fp32 kernels"""
+        return 3 * (wc + 2) * 32 * 5 <= 65536
 
     @staticmethod
     def _p16_ok(wc, c):

@@ -592,14 +592,23 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_k16_kernel(const unsigne
 }
 
 // dy (fp32, nullable) and/or dy_pad (bf16 in the zero-padded [N][Hc+2][Wc+2][C] layout of gemm_bf16.hip, nullable)
-template <typename DZ, typename PT, int NP, bool F16>
+//
+// The gather is branch-free: the ring rows carry two guard pixels on either side and rows outside the frame are guard rows, all
+// with an argmax word that matches no tap (0xFF bytes), so each of the nine taps is an unconditional pair of LDS reads, a byte
+// compare and a select. (With `continue`s around the out-of-frame taps hipcc built nine basic blocks, each waiting for its own
+// LDS reads and juggling exec masks: ~16 vector + 7 scalar instructions and one LDS round trip per tap; the counters show the
+// kernel bound by vector-instruction issue, profiles/r02_pool_counters.md.) Skipped taps and taps that add 0.0f give the same
+// sum bit for bit (the accumulator starts at +0 and can never be -0). Addresses: uniform row pointers + loop-invariant lane
+// offsets, ring rows as three rotating scalar offsets.
+// NP = passes of 32 pixels per pooled row, NC = per conv row (launcher: NC = NP or NP + 1).
+template <typename DZ, typename PT, int NP, int NC, bool F16>
 __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const uint8_t* __restrict__ idx,
                                                            const float* __restrict__ coef3, float* __restrict__ dy,
                                                            __hip_bfloat16* __restrict__ dy_pad,
                                                            double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C,
                                                            int bands) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // dp [3][Wp][CS] floats, then idx [3][Wp][CS] bytes
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // dp [3][Wp+4][CS] floats, then idx [3][Wp+4][CS] bytes
     const int tid = threadIdx.x, l8 = tid & 7, px = tid >> 3;
     const int ccn = C / CS;
     // Blocks b and b + 8 run on the same XCD (round-robin dispatch) at about the same time: give them the two 32-channel
@@ -607,50 +616,73 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
     unsigned vb = blockIdx.x;
     if ((gridDim.x & 15u) == 0) { const unsigned q = vb >> 4, r = vb & 15u; vb = ((q << 3) + (r & 7u)) * 2 + (r >> 3); }
     const int slot = vb / ccn, sl = vb % ccn, cb = sl * CS, c0 = cb + l8 * 4;
-    const int Hp = Hc - 2, Wp = Wc - 2;
-    uint32_t* sidx = reinterpret_cast<uint32_t*>(smem + 3 * Wp * CS);   // [3][Wp][8] words
+    const int Hp = Hc - 2, Wp = Wc - 2, Wg = Wp + 4;                   // ring row = 2 guard pixels + Wp pooled pixels + 2 guard pixels
+    char* ring = reinterpret_cast<char*>(smem);
+    char* iring = ring + (size_t)3 * Wg * CS * 4;                     // argmax words [3][Wg][8]
+    const unsigned drow = (unsigned)Wg * CS * 4, irow = (unsigned)Wg * CS;
     const float4 ca = *reinterpret_cast<const float4*>(coef3 + c0);
     const float4 cbv = *reinterpret_cast<const float4*>(coef3 + C + c0);
     const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + c0);
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // loop-invariant lane offsets (bytes): pooled pixel x = px + 32 ps in the input rows / in a ring row; conv pixel w = px + 32 ps
+    uint32_t zoff[NP], qoff[NP], ioff[NP], ldp[NP], lix[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int x = px + 32 * ps, xc = x < Wp ? x : Wp - 1;
+        zoff[ps] = (uint32_t)(((int64_t)xc * C + c0) * (int64_t)sizeof(DZ));
+        qoff[ps] = (uint32_t)(((int64_t)xc * C + c0) * (int64_t)sizeof(PT));
+        ioff[ps] = (uint32_t)(xc * CS + l8 * 4);
+        ldp[ps] = (uint32_t)(((x + 2) * CS + l8 * 4) * 4);
+        lix[ps] = (uint32_t)((x + 2) * CS + l8 * 4);
+    }
+    uint32_t yoff[NC], poff[NC], gdp[NC], gix[NC];
+#pragma unroll
+    for (int ps = 0; ps < NC; ++ps) {
+        const int w = px + 32 * ps, wc = w < Wc ? w : Wc - 1;          // lanes past the row gather a clamped pixel and store nothing
+        yoff[ps] = (uint32_t)(((int64_t)wc * C + c0) * 4);
+        poff[ps] = (uint32_t)(((int64_t)(wc + 1) * C + c0) * 2);
+        gdp[ps] = (uint32_t)(((wc + 2) * CS + l8 * 4) * 4);           // tap dw reads the ring pixel (w + 2 - dw)
+        gix[ps] = (uint32_t)((wc + 2) * CS + l8 * 4);
+    }
     for (int unit = slot; unit < N * bands; unit += (int)gridDim.x / ccn) {       // (frame, band of dy rows), as in the forward
         const int n = unit / bands, band = unit % bands;
         const int h0 = (int)((int64_t)Hc * band / bands), h1 = (int)((int64_t)Hc * (band + 1) / bands);
-        const DZ* dzn = dz + (int64_t)n * Hp * Wp * C + c0;
-        const PT* pn = p + (int64_t)n * Hp * Wp * C + c0;
-        const uint8_t* in = idx + ((int64_t)n * ccn + sl) * Hp * Wp * CS + l8 * 4;                            // slice-major, see idx_off
-        float* dyn = dy ? dy + (int64_t)n * Hc * Wc * C + c0 : nullptr;
-        __hip_bfloat16* dpn = dy_pad ? dy_pad + (int64_t)n * (Hc + 2) * (Wc + 2) * C + c0 : nullptr;
+        const int hfirst = h0 > 2 ? h0 - 2 : 0;                  // dy row h gathers from pooled rows h-2..h: two warm-up rows
+        const char* zrow = reinterpret_cast<const char*>(dz + ((int64_t)n * Hp + hfirst) * Wp * C);
+        const char* qrow = reinterpret_cast<const char*>(p + ((int64_t)n * Hp + hfirst) * Wp * C);
+        const char* xrow = reinterpret_cast<const char*>(idx + (((int64_t)n * ccn + sl) * Hp + hfirst) * Wp * CS);   // slice-major, see idx_off
+        const int64_t zstep = (int64_t)Wp * C * sizeof(DZ), qstep = (int64_t)Wp * C * sizeof(PT), xstep = (int64_t)Wp * CS;
+        char* dyr = dy ? reinterpret_cast<char*>(dy + ((int64_t)n * Hc + h0) * Wc * C) : nullptr;
+        char* dpr = dy_pad ? reinterpret_cast<char*>(dy_pad + (((int64_t)n * (Hc + 2) + h0 + 1) * (Wc + 2)) * C) : nullptr;
+        const int64_t ystep = (int64_t)Wc * C * 4, pstep = (int64_t)(Wc + 2) * C * 2;
+        __syncthreads();                                           // the previous unit's last gather
+        for (int i = tid; i < 3 * Wg * 8; i += 256) reinterpret_cast<uint32_t*>(iring)[i] = 0xFFFFFFFFu;       // every ring pixel: no tap
         __syncthreads();
         // Software pipeline over rows: the loads of pooled row h+1 (dz, p, argmax) are issued into registers before row h is
-        // gathered and land while it is computed. Without it every row paid a full global-load round trip between two
-        // barriers: ~9 MB in flight chip-wide = 3.6 TB/s, which is what the kernel measured.
-        // NP = passes of 32 pixels per pooled row (launcher: ceil(Wp / 32) <= 5). Every pass loads unconditionally, from a
-        // clamped address when its pixel or row is past the end (never consumed): with a branch around each pass hipcc cannot
-        // count the loads in flight and waits for nearly all of them before each use (vmcnt(2)), i.e. one memory round trip
-        // per pass; the bf16 form converts at the use, not at the load, for the same reason.
-        decltype(load_dz4_raw(dzn)) rd[NP];
-        decltype(load_dz4_raw(pn)) rq[NP];
+        // gathered and land while it is computed; every load is unconditional, from a clamped address past the end (never
+        // consumed), so that hipcc can count the loads in flight.
+        decltype(load_dz4_raw(dz)) rd[NP];
+        decltype(load_dz4_raw(p)) rq[NP];
         uint32_t ri[NP];
-        const int hfirst = h0 > 2 ? h0 - 2 : 0;                  // dy row h gathers from pooled rows h-2..h: two warm-up rows
-        auto prefetch = [&](int hr) {
-            const int hrc = hr < Hp ? hr : Hp - 1;
+        int fr = hfirst;                                           // the pooled row the input pointers are at
+        auto prefetch = [&]() {
 #pragma unroll
             for (int ps = 0; ps < NP; ++ps) {
-                const int x = px + 32 * ps, xc = x < Wp ? x : Wp - 1;
-                const int64_t o = ((int64_t)hrc * Wp + xc) * C;
-                rd[ps] = load_dz4_raw(dzn + o);
-                rq[ps] = load_dz4_raw(pn + o);
-                ri[ps] = *reinterpret_cast<const uint32_t*>(in + ((int64_t)hrc * Wp + xc) * CS);
+                rd[ps] = load_dz4_raw(reinterpret_cast<const DZ*>(zrow + zoff[ps]));
+                rq[ps] = load_dz4_raw(reinterpret_cast<const PT*>(qrow + qoff[ps]));
+                ri[ps] = *reinterpret_cast<const uint32_t*>(xrow + ioff[ps]);
             }
+            if (fr + 1 < Hp) { zrow += zstep; qrow += qstep; xrow += xstep; ++fr; }
         };
-        prefetch(hfirst);
+        unsigned o0 = 0, o1 = 1, o2 = 2;                           // ring slots of pooled rows h, h - 1, h - 2
+        prefetch();
         for (int h = hfirst; h < h1; ++h) {
+            char* drow0 = ring + o0 * drow;
+            char* irow0 = iring + o0 * irow;
             if (h < Hp) {       // pooled row h enters the rolling buffer as dp = a*dz + b*p + c
 #pragma unroll
                 for (int ps = 0; ps < NP; ++ps) {
-                    const int x = px + 32 * ps;
-                    if (x < Wp) {
+                    if (px + 32 * ps < Wp) {
                         const float4 d = dz4_of(rd[ps]), q = dz4_of(rq[ps]);
                         float4 v;
                         // the ReLU mask rides on p: every window whose argmax is a given conv pixel has p equal to that pixel's y
@@ -658,40 +690,48 @@ __global__ __launch_bounds__(256) void bnpool_bwd_v2_kernel(const DZ* __restrict
                         v.y = q.y > 0.f ? fmaf(ca.y, d.y, fmaf(cbv.y, q.y, cc.y)) : 0.f;
                         v.z = q.z > 0.f ? fmaf(ca.z, d.z, fmaf(cbv.z, q.z, cc.z)) : 0.f;
                         v.w = q.w > 0.f ? fmaf(ca.w, d.w, fmaf(cbv.w, q.w, cc.w)) : 0.f;
-                        *reinterpret_cast<float4*>(&smem[(((h % 3) * Wp) + x) * CS + l8 * 4]) = v;
-                        sidx[(((h % 3) * Wp) + x) * 8 + l8] = ri[ps];
+                        *reinterpret_cast<float4*>(drow0 + ldp[ps]) = v;
+                        *reinterpret_cast<uint32_t*>(irow0 + lix[ps]) = ri[ps];
                     }
                 }
+            } else {            // past the last pooled row: a guard row
+#pragma unroll
+                for (int ps = 0; ps < NP; ++ps)
+                    if (px + 32 * ps < Wp) *reinterpret_cast<uint32_t*>(irow0 + lix[ps]) = 0xFFFFFFFFu;
             }
-            if (h + 1 < h1) prefetch(h + 1);
+            if (h + 1 < h1) prefetch();
             __syncthreads();
-            for (int w = px; w < Wc && h >= h0; w += 32) {
-                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= h0) {
 #pragma unroll
-                for (int dh = 0; dh < 3; ++dh) {
-                    const int ph = h - dh;
-                    if ((unsigned)ph >= (unsigned)Hp) continue;
+                for (int ps = 0; ps < NC; ++ps) {
+                    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int pw = w - dw;
-                        if ((unsigned)pw >= (unsigned)Wp) continue;
-                        const int q = ((ph % 3) * Wp) + pw;
-                        const float4 v = *reinterpret_cast<const float4*>(&smem[q * CS + l8 * 4]);
-                        const uint32_t ii = sidx[q * 8 + l8];
-                        const unsigned k = dh * 3 + dw;
-                        a4.x += (ii & 0xffu) == k ? v.x : 0.f;
-                        a4.y += ((ii >> 8) & 0xffu) == k ? v.y : 0.f;
-                        a4.z += ((ii >> 16) & 0xffu) == k ? v.z : 0.f;
-                        a4.w += (ii >> 24) == k ? v.w : 0.f;
+                    for (int dh = 0; dh < 3; ++dh) {
+                        const unsigned o = dh == 0 ? o0 : dh == 1 ? o1 : o2;
+                        const char* dr = ring + o * drow + gdp[ps];
+                        const char* ir = iring + o * irow + gix[ps];
+#pragma unroll
+                        for (int dw = 0; dw < 3; ++dw) {
+                            const float4 v = *reinterpret_cast<const float4*>(dr - dw * (CS * 4));
+                            const uint32_t ii = *reinterpret_cast<const uint32_t*>(ir - dw * CS);
+                            const unsigned k = dh * 3 + dw;       // (SDWA byte compares into scalar masks via inline asm: 107 instead of
+                                                                  // 136 vector instructions per pass, and 5 % slower)
+                            a4.x += (ii & 0xffu) == k ? v.x : 0.f;
+                            a4.y += ((ii >> 8) & 0xffu) == k ? v.y : 0.f;
+                            a4.z += ((ii >> 16) & 0xffu) == k ? v.z : 0.f;
+                            a4.w += (ii >> 24) == k ? v.w : 0.f;
+                        }
+                    }
+                    if (px + 32 * ps < Wc) {
+                        if (dyr) *reinterpret_cast<float4*>(dyr + yoff[ps]) = a4;
+                        if (dpr) *reinterpret_cast<uint2*>(dpr + poff[ps]) = make_uint2(pack_h16x2<F16>(a4.x, a4.y), pack_h16x2<F16>(a4.z, a4.w));
+                        acc[0][0] += (double)a4.x; acc[0][1] += (double)a4.y; acc[0][2] += (double)a4.z; acc[0][3] += (double)a4.w;
                     }
                 }
-                const int64_t o = ((int64_t)h * Wc + w) * C;
-                if (dyn) *reinterpret_cast<float4*>(dyn + o) = a4;
-                if (dpn)
-                    *reinterpret_cast<uint2*>(dpn + ((int64_t)(h + 1) * (Wc + 2) + w + 1) * C) =
-                        make_uint2(pack_h16x2<F16>(a4.x, a4.y), pack_h16x2<F16>(a4.z, a4.w));
-                acc[0][0] += (double)a4.x; acc[0][1] += (double)a4.y; acc[0][2] += (double)a4.z; acc[0][3] += (double)a4.w;
+                if (dyr) dyr += ystep;
+                if (dpr) dpr += pstep;
             }
+            const unsigned t = o2; o2 = o1; o1 = o0; o0 = t;      // next row goes where row h - 2 was
             __syncthreads();
         }
     }
@@ -768,13 +808,16 @@ static void launch_bnpool_bwd_v2(int nparts, size_t lds, hipStream_t st, const D
                                  float* dy, __hip_bfloat16* dy_pad, double* dbias_partials, int N, int Hc, int Wc, int C) {
     const dim3 grid(nparts * (C / CS)), block(256);
     const int bands = row_bands(nparts, N, Hc);
-    switch ((Wc - 2 + 31) / 32) {                               // passes of 32 pixels per pooled row; the LDS limit keeps Wp <= 136
-    case 1: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 1, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 2: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 2, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 3: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 3, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    case 4: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 4, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
-    default: hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, 5, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands); break;
+    const int np = (Wc - 2 + 31) / 32, nc = (Wc + 31) / 32;    // passes of 32 pixels per pooled / conv row; the LDS limit keeps Wp <= 132
+#define GN_BWD2(NPV, NCV) hipLaunchKernelGGL((bnpool_bwd_v2_kernel<DZ, PT, NPV, NCV, F16>), grid, block, lds, st, dz, p, idx, coef3, dy, dy_pad, dbias_partials, N, Hc, Wc, C, bands)
+    switch (np * 2 + (nc - np)) {
+    case 2: GN_BWD2(1, 1); break;  case 3: GN_BWD2(1, 2); break;
+    case 4: GN_BWD2(2, 2); break;  case 5: GN_BWD2(2, 3); break;
+    case 6: GN_BWD2(3, 3); break;  case 7: GN_BWD2(3, 4); break;
+    case 8: GN_BWD2(4, 4); break;  case 9: GN_BWD2(4, 5); break;
+    case 10: GN_BWD2(5, 5); break; default: GN_BWD2(5, 6); break;
     }
+#undef GN_BWD2
 }
 
 bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C & 3) == 0 && (256 % (C >> 2)) == 0; }
@@ -897,7 +940,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd: bad dims");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd: alignment");
-    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    const size_t lds = (size_t)3 * (Wc + 2) * CS * (sizeof(float) + 1);      // three ring rows of Wp + 4 pixels: value + argmax byte
     if (C % CS == 0 && lds <= 64 * 1024 && !getenv("GOALNET_POOL_V1")) {
         const size_t need = lds < 8192 ? 8192 : lds;
         launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
@@ -917,7 +960,7 @@ int goalnet_bnpool_bwd_bf16p(const float* dz, const float* p, const uint8_t* idx
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: bad dims (C %% 32)");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p: alignment");
-    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    const size_t lds = (size_t)3 * (Wc + 2) * CS * (sizeof(float) + 1);      // three ring rows of Wp + 4 pixels: value + argmax byte
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
     if (f16) launch_bnpool_bwd_v2<float, float, true>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)dy_pad_bf16, dbias_partials, N, Hc, Wc, C);
@@ -935,7 +978,7 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
     GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C) && C % CS == 0, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: bad dims (C %% 32)");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) && aligned16(dy_pad_bf16) &&
                (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_bf16p_t: alignment");
-    const size_t lds = (size_t)3 * (Wc - 2) * CS * (sizeof(float) + 1);
+    const size_t lds = (size_t)3 * (Wc + 2) * CS * (sizeof(float) + 1);      // three ring rows of Wp + 4 pixels: value + argmax byte
     GN_REQUIRE(lds <= 64 * 1024, GOALNET_E_SHAPE, "bnpool_bwd_bf16p_t: image too wide for the rolling LDS rows");
     const size_t need = lds < 8192 ? 8192 : lds;
     hipStream_t st = (hipStream_t)stream;
