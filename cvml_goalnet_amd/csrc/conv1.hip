@@ -13,7 +13,7 @@ using namespace goalnet;
 namespace {
 
 constexpr int CO = 64, KP = 27;
-constexpr int WG_PARTS = 512;   // blocks (= partial rows) of the weight-gradient kernel
+constexpr int WG_PARTS = 768;   // blocks (= partial rows) of the weight-gradient kernel: three 576-thread blocks per CU (512: 1.23 ms, 768: 1.07, 1024: 1.20 at 1024 frames of 224x224)
 
 __device__ __forceinline__ int conv1_out(int x) { return (x + 3) / 3 + 1; }
 

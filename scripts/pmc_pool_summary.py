@@ -9,7 +9,7 @@ for d in ("pmc_a", "pmc_b", "pmc_c"):
         continue
     for r in csv.DictReader(open(fs[-1])):
         n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
-        if "pool" not in n and "bn_" not in n:
+        if "pool" not in n and "bn_" not in n and "conv1_" not in n and "adam" not in n:
             continue
         vals[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, cs in sorted(vals.items()):
