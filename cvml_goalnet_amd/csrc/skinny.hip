@@ -14,28 +14,31 @@ using namespace goalnet;
 namespace {
 
 constexpr int KT = 512;      // forward: K-slab per block (x slab in LDS: MR x KT floats = 24..32 KB -> 5..6 blocks per CU)
-constexpr int JB = 32;       // forward: output columns per block (two rounds of 4 per wave)
+// forward: a block computes 4 waves x CW columns x RN rounds. Long reductions (linear5: 81 K-slabs): CW = 4, RN = 1 (16 columns:
+// 2 592 blocks of ~100 VGPRs; RN = 2 measured 38 us against 35.5). The small layers (fusion MLP, AudBl linear: <= 2 K-slabs) had grids of 4 - 32
+// blocks that way and ran ~10 us each on a sixteenth of the chip: CW = 1, RN = 1 (4 columns per block, 32 - 128 blocks).
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // ---- forward: y[m][j] = epi(sum_k xa[m][k] w[j][k]); grid (ceil(J / 16), KS) --------------------------------------
-template <int MR>
+template <int MR, int CW, int RN>
 __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int bnC, const float* __restrict__ w,
                                                         EpiP ep, int M, int64_t K, int J, int KS) {
     __shared__ float xs[MR * KT];
+    constexpr int JB = 4 * CW * RN;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t k0 = (int64_t)blockIdx.y * KT;
     // all weight loads of the block (two rounds of 4 columns x KT) are issued first: they do not depend on x, and the HBM
     // round trip then overlaps the staging of the x slab instead of following it
-    float4 w4[JB / 16][KT / 256][4];
+    float4 w4[RN][KT / 256][CW];
 #pragma unroll
-    for (int rnd = 0; rnd < JB / 16; ++rnd)
+    for (int rnd = 0; rnd < RN; ++rnd)
 #pragma unroll
         for (int kk = 0; kk < KT / 256; ++kk)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = blockIdx.x * JB + rnd * 16 + wv * 4 + jj;
+            for (int jj = 0; jj < CW; ++jj) {
+                const int j = blockIdx.x * JB + rnd * 4 * CW + wv * CW + jj;
                 const int64_t k = k0 + kk * 256 + lane * 4;
                 w4[rnd][kk][jj] = (j < J && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -56,11 +59,11 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
     }
     __syncthreads();
 #pragma unroll
-    for (int rnd = 0; rnd < JB / 16; ++rnd) {
-        const int j0 = blockIdx.x * JB + rnd * 16 + wv * 4;
-        float acc[4][MR];
+    for (int rnd = 0; rnd < RN; ++rnd) {
+        const int j0 = blockIdx.x * JB + rnd * 4 * CW + wv * CW;
+        float acc[CW][MR];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < CW; ++jj)
 #pragma unroll
             for (int m = 0; m < MR; ++m) acc[jj][m] = 0.f;
 #pragma unroll
@@ -70,35 +73,38 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
             for (int m = 0; m < MR; ++m) {
                 const float4 x4 = *reinterpret_cast<const float4*>(&xs[m * KT + kl]);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[jj][m] += dot4(w4[rnd][kk][jj], x4);
+                for (int jj = 0; jj < CW; ++jj) acc[jj][m] += dot4(w4[rnd][kk][jj], x4);
             }
         }
         // lane jj * MR + m keeps the total of (column j0 + jj, row m): one parallel epilogue instead of 4 * MR serial ones
         float mine = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < CW; ++jj)
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 const float v = wave_sum_dpp(acc[jj][m]);
                 if (lane == jj * MR + m) mine = v;
             }
         const int m = lane % MR, j = j0 + lane / MR;
-        if (lane < 4 * MR && m < M && j < J) {
+        if (lane < CW * MR && m < M && j < J) {
             if (KS > 1) ep.out[(int64_t)blockIdx.y * ep.slab_stride + (int64_t)m * J + j] = mine;
             else ep.out[(int64_t)m * ep.ld + j] = epi_apply(ep, mine, m, j);
         }
     }
 }
 
-// ---- dX: dx[m][k] = (sum_j dy[m][j] w[j][k]) * mult[m][k]; grid ceil(K / 64); 16 j-groups x 16 k-float4 per block ----
-template <int MR>
+// ---- dX: dx[m][k] = (sum_j dy[m][j] w[j][k]) * mult[m][k]; grid ceil(K / (4 KL)); (256 / KL) j-groups x KL k-float4 per block.
+// KL = 16 for linear5 (64 k per block, 648 blocks; KL = 8 reads 128-byte pieces of the weight rows: 35 us against 24.5); KL = 4 for the small layers (16 k per block: 32 - 64 blocks instead of 8 - 16,
+// and 64 j-groups: 8 instead of 32 dependent steps per thread) ----
+template <int MR, int KL>
 __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ w,
                                                        const float* __restrict__ mult, int64_t ldmult, float* __restrict__ dx,
                                                        int64_t lddx, int M, int64_t K, int J) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // max(JC * MR, 16 * MR * 16 * 4) floats
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // max(JC * MR, 256 * MR * 4) floats
     constexpr int JC = 512;                                       // dy columns staged per round
-    const int tid = threadIdx.x, kl = tid & 15, jg = tid >> 4;
-    const int64_t k = (int64_t)blockIdx.x * 64 + kl * 4;
+    constexpr int JG = 256 / KL;
+    const int tid = threadIdx.x, kl = tid % KL, jg = tid / KL;
+    const int64_t k = (int64_t)blockIdx.x * (KL * 4) + kl * 4;
     const bool kok = k < K;
     float4 acc[MR];
 #pragma unroll
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
         }
         __syncthreads();
 #pragma unroll 4
-        for (int j = jg; j < jn; j += 16) {
+        for (int j = jg; j < jn; j += JG) {
             const float4 w4 = kok ? *reinterpret_cast<const float4*>(w + (int64_t)(jc + j) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int mq = 0; mq < MR / 4; ++mq) {
@@ -127,14 +133,14 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(sm);                  // red[jg][m][kl]
 #pragma unroll
-    for (int m = 0; m < MR; ++m) red[(jg * MR + m) * 16 + kl] = acc[m];
+    for (int m = 0; m < MR; ++m) red[(jg * MR + m) * KL + kl] = acc[m];
     __syncthreads();
-    const int m = tid >> 4;
+    const int m = tid / KL;
     if (m < MR && m < M && kok) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float4 v = red[(g * MR + m) * 16 + kl];
+#pragma unroll 16
+        for (int g = 0; g < JG; ++g) {
+            const float4 v = red[(g * MR + m) * KL + kl];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         if (mult) {
@@ -146,12 +152,13 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
 }
 
 // ---- dW: dw[j][k] = sum_m dy[m][j] xa[m][k]; grid (ceil(K / 1024), ceil(J / 32)); the thread keeps its M x-values -----
-template <int MR>
+// JR = output rows (j) per block: 16 for linear5 (1 312 blocks; 32 rows / 656 blocks measured 27.7 us against 23.0), 4 for the
+// small layers, whose grids were 4 - 16 blocks with 32
+template <int MR, int JR>
 __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                        int64_t ldx, const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int bnC, float* __restrict__ dw, float* __restrict__ db, int M, int64_t K,
                                                        int J) {
-    constexpr int JR = 32;
     __shared__ __attribute__((aligned(16))) float dys[JR * MR];
     const int tid = threadIdx.x;
     const int j0 = blockIdx.y * JR;
@@ -223,8 +230,13 @@ int skinny_linear_fwd(const float* x, int64_t ldx, const float* scale, const flo
     const int KS = skinny_fwd_splits(K);
     EpiP ep = efinal;
     if (KS > 1) ep = EpiP{EPI_RAW, (float*)ws, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
-    const dim3 grid((unsigned)((J + JB - 1) / JB), (unsigned)KS);
-    SKINNY_DISPATCH(M, hipLaunchKernelGGL(skinny_fwd_kernel<MR>, grid, dim3(256), 0, st, x, ldx, scale, shift, bnC, w, ep, M, K, J, KS));
+    if (KS >= 8) {
+        const dim3 grid((unsigned)((J + 15) / 16), (unsigned)KS);
+        SKINNY_DISPATCH(M, hipLaunchKernelGGL((skinny_fwd_kernel<MR, 4, 1>), grid, dim3(256), 0, st, x, ldx, scale, shift, bnC, w, ep, M, K, J, KS));
+    } else {
+        const dim3 grid((unsigned)((J + 3) / 4), (unsigned)KS);
+        SKINNY_DISPATCH(M, hipLaunchKernelGGL((skinny_fwd_kernel<MR, 1, 1>), grid, dim3(256), 0, st, x, ldx, scale, shift, bnC, w, ep, M, K, J, KS));
+    }
     GN_LAUNCH_CHECK("linear_fwd(skinny)");
     if (KS == 1) return 0;
     return launch_splitk_reduce("linear_fwd(skinny).reduce", (const float*)ws, KS, (int64_t)M * J, efinal, st);
@@ -232,19 +244,32 @@ int skinny_linear_fwd(const float* x, int64_t ldx, const float* scale, const flo
 
 int skinny_linear_dx(const float* dy, int64_t lddy, const float* w, const float* mult, int64_t ldmult, float* dx, int64_t lddx,
                      int M, int64_t K, int J, hipStream_t st) {
-    const dim3 grid((unsigned)((K + 63) / 64));
-    SKINNY_DISPATCH(M, {
-        const size_t a = (size_t)512 * MR * sizeof(float), b = (size_t)16 * MR * 16 * sizeof(float4);
-        hipLaunchKernelGGL(skinny_dx_kernel<MR>, grid, dim3(256), a > b ? a : b, st, dy, lddy, w, mult, ldmult, dx, lddx, M, K, J);
-    });
+    if (K > 4096) {
+        const dim3 grid((unsigned)((K + 63) / 64));
+        SKINNY_DISPATCH(M, {
+            const size_t a = (size_t)512 * MR * sizeof(float), b = (size_t)256 * MR * sizeof(float4);
+            hipLaunchKernelGGL((skinny_dx_kernel<MR, 16>), grid, dim3(256), a > b ? a : b, st, dy, lddy, w, mult, ldmult, dx, lddx, M, K, J);
+        });
+    } else {
+        const dim3 grid((unsigned)((K + 15) / 16));
+        SKINNY_DISPATCH(M, {
+            const size_t a = (size_t)512 * MR * sizeof(float), b = (size_t)256 * MR * sizeof(float4);
+            hipLaunchKernelGGL((skinny_dx_kernel<MR, 4>), grid, dim3(256), a > b ? a : b, st, dy, lddy, w, mult, ldmult, dx, lddx, M, K, J);
+        });
+    }
     GN_LAUNCH_CHECK("linear_bwd_dx(skinny)");
     return 0;
 }
 
 int skinny_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* scale, const float* shift, int bnC,
                      float* dw, float* db, int M, int64_t K, int J, hipStream_t st) {
-    const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)((J + 31) / 32));
-    SKINNY_DISPATCH(M, hipLaunchKernelGGL(skinny_dw_kernel<MR>, grid, dim3(256), 0, st, dy, lddy, x, ldx, scale, shift, bnC, dw, db, M, K, J));
+    if (K > 4096) {
+        const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)((J + 15) / 16));
+        SKINNY_DISPATCH(M, hipLaunchKernelGGL((skinny_dw_kernel<MR, 16>), grid, dim3(256), 0, st, dy, lddy, x, ldx, scale, shift, bnC, dw, db, M, K, J));
+    } else {
+        const dim3 grid((unsigned)((K + 1023) / 1024), (unsigned)((J + 3) / 4));
+        SKINNY_DISPATCH(M, hipLaunchKernelGGL((skinny_dw_kernel<MR, 4>), grid, dim3(256), 0, st, dy, lddy, x, ldx, scale, shift, bnC, dw, db, M, K, J));
+    }
     GN_LAUNCH_CHECK("linear_bwd_dw(skinny)");
     return 0;
 }
