@@ -28,15 +28,22 @@ __global__ __launch_bounds__(256) void transpose_inner_kernel(const float* __res
     }
 }
 
+// wt[ci][8 - t][co] = w[co][t][ci]: per tap a [Cout][Cin] -> [Cin][Cout] transpose through a 32 x 33 LDS tile, coalesced on both
+// sides (the element-per-thread gather it replaces read one 4-byte word per cache line: 9.6 us for conv3's 1.2 M weights, in
+// every backward of the 10-frame loop). blockIdx.y = tap.
 __global__ __launch_bounds__(256) void weight_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin) {
-    const int total = Cout * Cin * 9;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        // i indexes wt[ci][t'][co]
-        const int co = i % Cout;
-        const int t = (i / Cout) % 9;
-        const int ci = i / (Cout * 9);
-        wt[i] = w[((int64_t)co * 9 + (8 - t)) * Cin + ci];
-    }
+    __shared__ float tile[32][33];
+    const int t = blockIdx.y;
+    const int tiles_ci = (Cin + 31) / 32;
+    const int co0 = (blockIdx.x / tiles_ci) * 32, ci0 = (blockIdx.x % tiles_ci) * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = r0; r < 32; r += 8)
+        tile[r][c] = (co0 + r < Cout && ci0 + c < Cin) ? w[((int64_t)(co0 + r) * 9 + t) * Cin + ci0 + c] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = r0; r < 32; r += 8)
+        if (ci0 + r < Cin && co0 + c < Cout) wt[((int64_t)(ci0 + r) * 9 + (8 - t)) * Cout + co0 + c] = tile[c][r];
 }
 
 }  // namespace
@@ -57,10 +64,8 @@ int goalnet_transpose_inner(const float* src, float* dst, int64_t B, int64_t R, 
 int goalnet_conv3x3_weight_flip(const float* w_ohwi, float* wt, int Cout, int Cin, void* stream) {
     GN_REQUIRE(w_ohwi && wt, GOALNET_E_NULL, "conv3x3_weight_flip: null pointer");
     GN_REQUIRE(Cout > 0 && Cin > 0 && (int64_t)Cout * Cin * 9 < (1ll << 30), GOALNET_E_SHAPE, "conv3x3_weight_flip: bad dims");
-    const int total = Cout * Cin * 9;
-    int blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(weight_flip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_ohwi, wt, Cout, Cin);
+    const int tiles = ((Cout + 31) / 32) * ((Cin + 31) / 32);
+    hipLaunchKernelGGL(weight_flip_kernel, dim3(tiles, 9), dim3(256), 0, (hipStream_t)stream, w_ohwi, wt, Cout, Cin);
     GN_LAUNCH_CHECK("conv3x3_weight_flip");
     return 0;
 }
