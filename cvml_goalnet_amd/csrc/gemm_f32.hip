@@ -86,6 +86,7 @@ struct KCLoader {
         int convC;
     };
     static constexpr bool KC = true;
+    static constexpr bool ONE_STAGE = false;      // as the A operand (linear5 forward / dX): two LDS stages, see launch_gemm
     __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned voff[4], vaff;
     int bnC, convC;
@@ -137,6 +138,7 @@ struct MCLoader {
         const float* scale; const float* shift; int bnC;
     };
     static constexpr bool KC = false;
+    static constexpr bool ONE_STAGE = true;
     const float* x;
     int64_t ld;
     int kred, k0;
@@ -189,6 +191,7 @@ struct ConvALoader {
         const float* scale; const float* shift;
     };
     static constexpr bool KC = true;
+    static constexpr bool ONE_STAGE = true;
     __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned mask[4];
     unsigned voff, vaff, vmask;
@@ -508,11 +511,11 @@ __device__ __forceinline__ void store_acc_n64(const EpiP& ep, const f32x16 (&acc
 // Round 2: a two-deep register prefetch for the weight gradient (loads of K-tile kt + 2 issued before the MFMAs of tile kt,
 // two register sets and loader instances alternating; 248 VGPRs, no spill) measured 116.4 vs 116.6 TF/s at 128 frames:
 // memory latency is not what holds it at 0.69-0.74 of peak either. Removed.
-template <class AL, class BL, bool N64 = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
+template <class AL, class BL, bool N64 = false, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split, int xcd_splits) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[STAGES][2][OP_FLOATS];
     const int tid = threadIdx.x;
     int tm, tn, split;
     if (xcd_splits > 0) {
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
     }
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
+        const int cur = STAGES == 1 ? 0 : (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
         if (more) {
             // the buffer being filled was last read in iteration kt-1, which every wave left through the barrier
@@ -581,11 +584,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(typename AL::P ap, typ
         }
         if constexpr (N64) compute_tile_n64(lds[cur][0], lds[cur][1], acc[0], wave, r, h);
         else compute_tile<AL::KC, BL::KC>(lds[cur][0], lds[cur][1], acc, wm, wn, r, h);
+        if constexpr (STAGES == 1) __syncthreads();      // one LDS stage (32 KB: three blocks per CU): every wave has read it
         if (more) {
             al.finish(ra);
             bl.finish(rb);
-            store_tile<AL::KC>(lds[cur ^ 1][0], ra, tid);
-            store_tile<BL::KC>(lds[cur ^ 1][1], rb, tid);
+            store_tile<AL::KC>(lds[STAGES == 1 ? 0 : cur ^ 1][0], ra, tid);
+            store_tile<BL::KC>(lds[STAGES == 1 ? 0 : cur ^ 1][1], rb, tid);
         }
         __syncthreads();
     }
@@ -668,6 +672,19 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     const bool xcd_local = nsplit >= 8 && tiles_m * tiles_n <= 256 && tiles_m * tiles_n * ((nsplit + 7) / 8 * 8) < (1ll << 31);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
     if (xcd_local) grid = dim3((unsigned)(tiles_m * tiles_n * ((nsplit + 7) / 8 * 8)), 1, 1);
+    // One LDS stage (32 KB, two barriers per K-tile) lets three blocks share a CU instead of two: while one block sits in its
+    // barrier / staging section two others have matrix work. Measured at 128 frames (TF/s, two stages -> one): conv3 forward
+    // 130.4 -> 134.7, data gradient 133.4 -> 140.4, weight gradient 132.1 -> 133.4, conv2 forward 105.7 -> 109.5, linear5 dW
+    // 91.3 -> 96.1; linear5 forward 121.9 -> 99.7 and dX 116.4 -> 114.7 (a K-contiguous A operand with a 10 MB row stride): by
+    // the A loader's trait. GOALNET_F32_STAGES=1|2 forces one form (tests, A/B runs).
+    static const int force_stages = getenv("GOALNET_F32_STAGES") ? atoi(getenv("GOALNET_F32_STAGES")) : 0;
+    const bool one_stage = force_stages == 1 || (force_stages != 2 && AL::ONE_STAGE);
+    if (one_stage && !N64) {
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, false, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+                           m_fast, ktiles, kps, xcd_local ? nsplit : 0);
+        GN_LAUNCH_CHECK(name);
+        return 0;
+    }
     hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, N64>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
                        m_fast, ktiles, kps, xcd_local ? nsplit : 0);
     GN_LAUNCH_CHECK(name);
@@ -767,7 +784,13 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
 }  // extern "C"
 namespace {
 // the kernel template a launch_gemm<AL, BL> call instantiates, as the compiler spells its arguments
-template <class AL, class BL, bool N64> const char* gemm_f32_kernel_name() { return __PRETTY_FUNCTION__; }
+template <class AL, class BL, bool N64, int STAGES> const char* gemm_f32_kernel_name_() { return __PRETTY_FUNCTION__; }
+// as launch_gemm dispatches: one LDS stage by the A loader's trait (not for the 128 x 64 tile), GOALNET_F32_STAGES forces one form
+template <class AL, class BL, bool N64> const char* gemm_f32_kernel_name() {
+    const int force = getenv("GOALNET_F32_STAGES") ? atoi(getenv("GOALNET_F32_STAGES")) : 0;
+    const bool one = !N64 && (force == 1 || (force != 2 && AL::ONE_STAGE));
+    return one ? gemm_f32_kernel_name_<AL, BL, false, 1>() : gemm_f32_kernel_name_<AL, BL, N64, 2>();
+}
 }
 extern "C" {
 
