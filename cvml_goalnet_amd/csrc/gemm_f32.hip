@@ -87,6 +87,7 @@ struct KCLoader {
     };
     static constexpr bool KC = true;
     static constexpr bool ONE_STAGE = false;      // as the A operand (linear5 forward / dX): two LDS stages, see launch_gemm
+    static constexpr int ONE_STAGE_BLOCKS = 3;
     __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned voff[4], vaff;
     int bnC, convC;
@@ -139,6 +140,7 @@ struct MCLoader {
     };
     static constexpr bool KC = false;
     static constexpr bool ONE_STAGE = true;
+    static constexpr int ONE_STAGE_BLOCKS = 4;    // blocks per CU with one LDS stage (register budget 128; 3: budget 168)
     const float* x;
     int64_t ld;
     int kred, k0;
@@ -192,6 +194,7 @@ struct ConvALoader {
     };
     static constexpr bool KC = true;
     static constexpr bool ONE_STAGE = true;
+    static constexpr int ONE_STAGE_BLOCKS = AFFINE ? 3 : 4;      // with the affine the loop spills at a budget of 128 registers (111 TF/s)
     __amdgpu_buffer_rsrc_t rx, rsc, rsh;
     unsigned mask[4];
     unsigned voff, vaff, vmask;
@@ -512,7 +515,7 @@ __device__ __forceinline__ void store_acc_n64(const EpiP& ep, const f32x16 (&acc
 // two register sets and loader instances alternating; 248 VGPRs, no spill) measured 116.4 vs 116.6 TF/s at 128 frames:
 // memory latency is not what holds it at 0.69-0.74 of peak either. Removed.
 template <class AL, class BL, bool N64 = false, int STAGES = 2>
-__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
+__global__ __launch_bounds__(256, STAGES == 1 ? (N64 ? 4 : AL::ONE_STAGE_BLOCKS) : 2) void gemm_f32_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                           int tiles_m, int tiles_n, int m_fast,
                                                           int ktiles, int ktiles_per_split, int xcd_splits) {
     __shared__ __attribute__((aligned(16))) float lds[STAGES][2][OP_FLOATS];
@@ -679,8 +682,8 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     // the A loader's trait. GOALNET_F32_STAGES=1|2 forces one form (tests, A/B runs).
     static const int force_stages = getenv("GOALNET_F32_STAGES") ? atoi(getenv("GOALNET_F32_STAGES")) : 0;
     const bool one_stage = force_stages == 1 || (force_stages != 2 && AL::ONE_STAGE);
-    if (one_stage && !N64) {
-        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, false, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
+    if (one_stage) {        // the 128 x 64 tile as well: conv2's data gradient 108.9 -> 123.1 TF/s
+        hipLaunchKernelGGL((gemm_f32_kernel<AL, BL, N64, 1>), grid, dim3(256), 0, st, ap, bp, ep, (int)tiles_m, (int)tiles_n,
                            m_fast, ktiles, kps, xcd_local ? nsplit : 0);
         GN_LAUNCH_CHECK(name);
         return 0;
@@ -785,11 +788,11 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
 namespace {
 // the kernel template a launch_gemm<AL, BL> call instantiates, as the compiler spells its arguments
 template <class AL, class BL, bool N64, int STAGES> const char* gemm_f32_kernel_name_() { return __PRETTY_FUNCTION__; }
-// as launch_gemm dispatches: one LDS stage by the A loader's trait (not for the 128 x 64 tile), GOALNET_F32_STAGES forces one form
+// as launch_gemm dispatches: one LDS stage by the A loader's trait, GOALNET_F32_STAGES forces one form
 template <class AL, class BL, bool N64> const char* gemm_f32_kernel_name() {
     const int force = getenv("GOALNET_F32_STAGES") ? atoi(getenv("GOALNET_F32_STAGES")) : 0;
-    const bool one = !N64 && (force == 1 || (force != 2 && AL::ONE_STAGE));
-    return one ? gemm_f32_kernel_name_<AL, BL, false, 1>() : gemm_f32_kernel_name_<AL, BL, N64, 2>();
+    const bool one = force == 1 || (force != 2 && AL::ONE_STAGE);
+    return one ? gemm_f32_kernel_name_<AL, BL, N64, 1>() : gemm_f32_kernel_name_<AL, BL, N64, 2>();
 }
 }
 extern "C" {
