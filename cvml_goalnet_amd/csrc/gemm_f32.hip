@@ -10,9 +10,8 @@
 //
 // Geometry: 256 threads = 4 waves (one per SIMD), block tile 128 x 128 x 32, wave tile 64 x 64 =
 // 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs). Operands are staged global -> registers -> LDS
-// (the A loader applies an affine and zero padding on the way, so LDS-DMA is not usable) with the next
-// K-tile's global loads in flight under the current tile's 64 MFMAs per wave; LDS holds two stages (2 blocks
-// per CU) or one (3 - 4 blocks per CU, a second barrier per K-tile) — see launch_gemm.
+// (the A loader applies an affine and zero padding on the way, so LDS-DMA is not usable), double-buffered
+// in LDS with the next K-tile's global loads in flight under the current tile's 64 MFMAs per wave.
 // An fp32 MFMA occupies its SIMD for 64 cycles, so the 4096 MFMA cycles per K-tile per wave cover the
 // 8 global loads + 8 LDS writes + 16-32 LDS reads a thread issues per K-tile with room to spare.
 //
