@@ -31,9 +31,10 @@ struct KCLoaderH {
     static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[4];
-    int wave;
-    __device__ KCLoaderH(const P& p, int row0, int tid) {
-        const int nrows = p.rows - row0 < BM ? p.rows - row0 : BM;
+    int wave, npieces;         // pieces (8 rows each) that hold rows of the matrix: the others are not staged at all
+    __device__ KCLoaderH(const P& p, int row0, int tid, int tile_rows = BM) {
+        const int nrows = p.rows - row0 < tile_rows ? p.rows - row0 : tile_rows;
+        npieces = tile_rows / 8;
         rx = make_rsrc(p.x + (int64_t)row0 * p.ld, clamp_u32((int64_t)nrows * p.ld * 2));
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
@@ -46,7 +47,8 @@ struct KCLoaderH {
     }
     __device__ __forceinline__ void issue(int kt, char* l) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(rx, l + (wave * 4 + i) * 8 * ROWB, voff[i], (unsigned)kt * ROWB);
+        for (int i = 0; i < 4; ++i)
+            if (wave * 4 + i < npieces) dma16(rx, l + (wave * 4 + i) * 8 * ROWB, voff[i], (unsigned)kt * ROWB);
     }
 };
 
@@ -377,11 +379,12 @@ __device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&a
     }
 }
 
+// N64: the B tile is 64 rows (8 KB; waves 2, 3 stage nothing of it): 24 KB per stage, three blocks per CU
 template <class AL, class BL, bool F16, bool N64 = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
+__global__ __launch_bounds__(256, N64 ? 3 : 2) void gemm_bf16_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                            int tiles_m, int tiles_n, int m_fast,
                                                            int ktiles, int ktiles_per_split) {
-    __shared__ __attribute__((aligned(16))) char lds[2][2][OP_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[2][N64 ? 3 * OP_BYTES / 2 : 2 * OP_BYTES];
     const int tid = threadIdx.x;
     int tm, tn;
     tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
 
     static_assert(!N64 || (!AL::TR && !BL::TR), "the 128 x 64 tile reads K-contiguous LDS images");
     const AL al(ap, tm * BM, tid);
-    const BL bl(bp, tn * (N64 ? 64 : BN), tid);
+    const BL bl = [&] { if constexpr (N64) return BL(bp, tn * 64, tid, 64); else return BL(bp, tn * BN, tid); }();
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -405,19 +408,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(typename AL::P ap, ty
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (kt0 < kt1) {
-        al.issue(kt0, lds[0][0]);
-        bl.issue(kt0, lds[0][1]);
+        al.issue(kt0, lds[0]);
+        bl.issue(kt0, lds[0] + OP_BYTES);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         if (kt + 1 < kt1) {     // the buffer being filled was last read in iteration kt-1, left through the barrier
-            al.issue(kt + 1, lds[cur ^ 1][0]);
-            bl.issue(kt + 1, lds[cur ^ 1][1]);
+            al.issue(kt + 1, lds[cur ^ 1]);
+            bl.issue(kt + 1, lds[cur ^ 1] + OP_BYTES);
         }
-        if constexpr (N64) compute_tile_h_n64<F16>(lds[cur][0], lds[cur][1], acc[0], wave, lane);
-        else compute_tile_h<AL::TR, BL::TR, F16>(lds[cur][0], lds[cur][1], acc, wm, wn, lane);
+        if constexpr (N64) compute_tile_h_n64<F16>(lds[cur], lds[cur] + OP_BYTES, acc[0], wave, lane);
+        else compute_tile_h<AL::TR, BL::TR, F16>(lds[cur], lds[cur] + OP_BYTES, acc, wm, wn, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA data has landed before anyone passes the barrier
         __syncthreads();
     }
