@@ -34,6 +34,8 @@ Objects on the JSON line:
                 (the same 16-bit engine with bfloat16 / IEEE binary16 storage; fp16 adds a loss scale and an overflow guard).
   comm          (N > 1) ranks, exchange mode, bytes per bucket, a stand-alone all-reduce of bucket 1 (algorithm bandwidth)
                 and the exposed (non-overlapped) wait per step, max over ranks.
+  dropin_path   /root/reference/main.py:187-196 verbatim on this AVM (CPU tensors, nn.MSELoss, stock optim.Adam) at 40x40 / N = 10 and at
+                224x224 / N = 64, us per step, with the fused device-resident step beside it.
   native_40x40_loop  SURVEY.md §8(d) "report additionally frames/s at the reference-native 40x40": the reference's own
                 operating point (main.py:169-198: one video at a time, 10 frames per optimizer step, fp32), run by
                 loop.VideoTrainer as one HIP-graph launch per sub-batch, with the CPU oracle's step beside it; N = 1 only.
@@ -163,8 +165,32 @@ def logit_parity(model, h, w, seed):
             "max_abs_logit": ref_logit.abs().max().item(), "frames": n}
 
 
+def host_cpu_info():
+    """CPU model string, physical cores (distinct (socket, core id) pairs) and hardware threads of this host, from /proc/cpuinfo"""
+    model, cores, phys, core = None, set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return {"cpu_model": model, "physical_cores": len(cores) or None, "hardware_threads": os.cpu_count()}
+
+
 def cpu_baseline(model, h, w, seed, max_seconds=40.0):
-    """Time the oracle's train step on the host cores (bounded sample: one clip per step)."""
+    """Time the oracle's train step on the host cores (bounded sample: one clip per step), and — BASELINE.json config 1 / SURVEY.md
+    §8(d) — the oracle's forward alone on one 16-frame clip (utils.py:260-272 under no_grad), with the HIP forward of the same clip."""
     from cvml_goalnet_amd import synth
     from oracle import avm_ref
     n = FRAMES_PER_CLIP
@@ -186,9 +212,35 @@ def cpu_baseline(model, h, w, seed, max_seconds=40.0):
         if time.time() - t_begin > max_seconds:
             break
     t = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"oracle train step (fwd+MSE+bwd+Adam) on {n} frames (1 clip) of {h}x{w}, fp32, torch {torch.__version__} CPU, "
-                      f"{len(times)} steps, best of the non-first: {t:.2f} s/step"}
+    # config 1: forward only, one clip, on the updated weights (the cost does not depend on their values)
+    fts = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.time()
+            avm_ref.forward(p, {k: v.clone() for k, v in b.items()}, a_c if model.audio_included else None, v_c, masks, model.audio_included)
+            fts.append(time.time() - t0)
+    tf = min(fts[1:])
+    bn_backup = {k: getattr(*model._module_of(k)).clone() for k in b}
+    hts = []
+    with torch.no_grad():
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.forward_device(aud if model.audio_included else None, vis, save=False)
+            torch.cuda.synchronize()
+            hts.append(time.perf_counter() - t0)
+    for k, v in bn_backup.items():
+        getattr(*model._module_of(k)).copy_(v)
+    info = host_cpu_info()
+    out = {"value": (n / FRAMES_PER_CLIP) / t, "unit": "clips/s", "cores": threads, "kind": "port",
+           "sample": f"oracle train step (fwd+MSE+bwd+Adam) on {n} frames (1 clip) of {h}x{w}, fp32, torch {torch.__version__} CPU, "
+                     f"{len(times)} steps, best of the non-first: {t:.2f} s/step; {threads} ATen threads on {info['cpu_model']} "
+                     f"({info['physical_cores']} physical cores, {info['hardware_threads']} hardware threads)"}
+    out.update(info)
+    out["cfg1_cpu_forward"] = {"what": f"BASELINE.json config 1: forward only (no_grad, train-mode BN) on one {n}-frame clip of {h}x{w}, CPU oracle",
+                               "ms": 1e3 * tf, "clips_per_s": 1.0 / tf, "threads": threads,
+                               "hip_forward_ms_same_clip": 1e3 * min(hts[1:]), "hip_clips_per_s": 1.0 / min(hts[1:])}
+    return out
 
 
 def roofline_of(events, dtype, n, h, w, clips):
@@ -340,6 +392,57 @@ def native40_loop(dev, frames=300, videos=3):
             "us_per_step": 1e6 * dt / steps, "frames_per_step": 10, "h": 40, "w": 40,
             "dtype": "f32", "mode": "one HIP graph launch per sub-batch (loop.VideoTrainer)", "graph_replays": tr.replays,
             "eager_steps": tr.eager_steps, "videos": videos, "frames_per_video": frames, "last_batch_loss": batch_loss}
+
+
+def dropin_path(dev, h, n, steps, warmup):
+    """The path "drops into the existing scripts" means: /root/reference/main.py:187-196 verbatim — CPU tensors in, `nn.MSELoss` with
+    its (n,1) x (n,) broadcast, autograd filling `.grad` of 30 strided Parameter views, stock `optim.Adam` created BEFORE the first
+    forward (main.py:70), two host syncs per step (`.item()`, `.tolist()`) — with the fused device-resident step beside it."""
+    import warnings
+    import torch.nn as nn
+    import torch.optim as optim
+    from cvml_goalnet_amd import AVM, synth
+    torch.manual_seed(4321)
+    frame_importance_model = AVM(audio_included=True, device=dev)
+    criterion = nn.MSELoss()                                                                  # main.py:68
+    optimizer = optim.Adam(params=frame_importance_model.parameters(), lr=0.001)              # main.py:70
+    sub_frames = torch.from_numpy(synth.make_visual(n, h, h))                                 # CPU tensors, as the dataset yields them
+    sub_audios = torch.from_numpy(synth.make_audio(n))
+    sub_labels = torch.from_numpy(synth.make_labels(n))
+    batch_loss, batch_predictions = 0.0, []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                                       # torch warns about the (n,1) x (n,) broadcast
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            optimizer.zero_grad()                                                             # main.py:187
+            subbatch_predictions = frame_importance_model(sub_audios, sub_frames)             # main.py:188
+            subbatch_loss = criterion(subbatch_predictions, sub_labels)                       # main.py:191
+            subbatch_loss.backward()                                                          # main.py:192
+            optimizer.step()                                                                  # main.py:193
+            batch_loss += subbatch_loss.item()                                                # main.py:195
+            batch_predictions.extend(subbatch_predictions.flatten().tolist())                 # main.py:196
+    torch.cuda.synchronize()
+    t_drop = (time.perf_counter() - t0) / steps
+    del optimizer, frame_importance_model
+    torch.cuda.empty_cache()
+    torch.manual_seed(4321)
+    m = AVM(audio_included=True, device=dev)
+    a, v, l = sub_audios.to(dev), sub_frames.to(dev), sub_labels.to(dev)
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        m.train_step(a, v, l)
+    torch.cuda.synchronize()
+    t_fused = (time.perf_counter() - t0) / steps
+    del m
+    torch.cuda.empty_cache()
+    return {"frames_per_step": n, "h": h, "w": h, "steps": steps, "dropin_us_per_step": 1e6 * t_drop, "fused_train_step_us_per_step": 1e6 * t_fused,
+            "dropin_frames_per_s": n / t_drop, "last_loss": subbatch_loss.item(),
+            "what": "main.py:187-196 verbatim (CPU tensors, nn.MSELoss, autograd, stock optim.Adam over 30 strided views, .item() + .tolist()) vs "
+                    "AVM.train_step on device tensors, eager launches (no graph)"}
 
 
 def comm_probe(model, dev, world):
@@ -520,6 +623,11 @@ def main():
                 except Exception as e:
                     log(f"native 40x40 loop failed: {e!r}")
                     res["native_40x40_loop"] = None
+                try:
+                    res["dropin_path"] = {"n10_h40": dropin_path(dev, 40, 10, 60, 10), "n64_h224": dropin_path(dev, 224, 64, 5, 2)}
+                except Exception as e:
+                    log(f"drop-in path timing failed: {e!r}")
+                    res["dropin_path"] = None
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)

@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOALNET_LIB_PATH") or os.path.join(_HERE, "libgoalnet_hip.so")   # override: A/B builds of the kernels
-ABI_VERSION = 1
+ABI_VERSION = 2
 STAT_PARTS = 1024
 
 P = c_void_p  # device pointers and the stream travel as void*
@@ -105,6 +105,7 @@ PROTOTYPES = {
     "goalnet_scale": (c_int, [P, c_int64, c_float, P]),
     "goalnet_grad_finite_check": (c_int, [P, c_int64, P, c_int64, P, P, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
+    "goalnet_counters_add4_guarded": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
     "goalnet_frames_preprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "goalnet_knapsack_ws_bytes": (c_size_t, [c_int, c_int]),

@@ -128,12 +128,15 @@ class AVM(nn.Module):
         # cores with fp32 accumulation; statistics, master weights, parameter gradients and Adam stay fp32.
         # fp16 keeps 11 significand bits against bf16's 8 (~8 x less rounding noise in the logits) but has 5 exponent bits:
         # the activation gradients it stores need a loss scale (loss_scale, below) and an overflow guard.
-        self.precision = precision     # property: also sets _half / _h16
         # dL/dpred is multiplied by the loss scale before backward, the fused Adam divides it out again (a power of two: exact).
-        # None (fp16 default) = 2^(10 + ceil(log2 n)) for a step of n frames: dL/dpred is O(1/n) and the 16-bit activation
+        # None (fp16 default) = 2^(10 + ceil(log2 n) - backoff) for a step of n frames: dL/dpred is O(1/n) and the 16-bit activation
         # gradients measured with scripts/grad_ranges.py (medians 6e-10 .. 1e-8, maxima 2e-7 .. 8e-6 at n = 1 024; ~1000 x that at
-        # n = 10) then sit at 6e-4 .. 8 — inside binary16's normal range [6.1e-5, 65504] with four orders of magnitude of headroom
-        self.loss_scale = None if precision == "fp16" else 1.0
+        # n = 10) then sit at 6e-4 .. 8 — inside binary16's normal range [6.1e-5, 65504] with four orders of magnitude of headroom.
+        # The precision setter picks the default (None for fp16, 1.0 otherwise) unless the user assigned `loss_scale` explicitly.
+        self._loss_scale, self._loss_scale_user = 1.0, False
+        self._loss_scale_backoff = 0   # halvings of the automatic scale (update_loss_scale: one per check that found skipped steps)
+        self._skipped_seen = 0
+        self.precision = precision     # property: also sets _half / _h16 and the default loss scale
         self._guard = None             # fp16: int64[2] device counters — step stamped as overflowed, number of skipped updates
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
@@ -204,6 +207,24 @@ class AVM(nn.Module):
         self._half = value in ("bf16", "fp16")
         self._h16 = torch.float16 if value == "fp16" else torch.bfloat16     # the 16-bit storage format of the GEMM operands
         self._w5b, self._w5b_version = None, None                              # a copy in the other format is not reusable
+        self._padbufs, self._padgen = {}, {}                                   # nor are the cached padded 16-bit operand buffers
+        if not self._loss_scale_user:
+            # binary16's 5 exponent bits need the scale (its activation gradients would flush to zero without it, and the overflow
+            # guard cannot see an underflow); bf16 / fp32 do not
+            self._loss_scale = None if value == "fp16" else 1.0
+            self._loss_scale_backoff = 0
+
+    @property
+    def loss_scale(self):
+        return self._loss_scale
+
+    @loss_scale.setter
+    def loss_scale(self, value):
+        """an explicit scale (a power of two keeps the unscale exact), or None = the automatic per-size scale of precision="fp16"; an
+        explicit value survives later changes of `precision`"""
+        self._loss_scale = None if value is None else float(value)
+        self._loss_scale_user = value is not None
+        self._loss_scale_backoff = 0
 
     # ------------------------------------------------------------------------------------------
     # parameter arena
@@ -326,7 +347,13 @@ class AVM(nn.Module):
         if not self._materialized:
             raise RuntimeError("state_dict() before the first forward / load_state_dict(): parameters are uninitialised")
         if self.grad_sync is not None:
-            self.grad_sync.gather_master(self)           # ddp.GradSync(shard_linear5=True): a collective when slices are stale
+            # ddp.GradSync(shard_linear5=True) in a 16-bit mode leaves the fp32 master of the other ranks' slices of linear5.weight
+            # stale between steps. Bringing it up to date is a COLLECTIVE: state_dict() does not issue it behind the caller's back
+            # (`if rank == 0: torch.save(model.state_dict())` would hang) — every rank calls grad_sync.consolidate(model) first.
+            if self.grad_sync.master_stale:
+                raise GoalnetError("state_dict(): foreign slices of visbl.linear5.weight's fp32 master are stale (GradSync(shard_linear5=True) "
+                                   "in a 16-bit mode); call model.grad_sync.consolidate(model) on EVERY rank first (a collective)")
+            self.grad_sync.wait_weights()                # fp32 + sharded: the in-flight all-gather of the updated weights (local wait)
         out = {} if destination is None else destination
         order = self._reference_key_order()
         for name in order:
@@ -371,6 +398,11 @@ class AVM(nn.Module):
         l2 = state_dict["audbl.linear3.weight"].shape[1] // 128 if self.audio_included else 0
         self._load_count += 1
         self._materialize(hw3, l2, init=False)
+        if self.grad_sync is not None:
+            # every slice of the master is about to be overwritten from the file (load_state_dict runs on all ranks, as in the
+            # reference's single process): an in-flight gather must land first, and nothing is stale afterwards
+            self.grad_sync.wait_weights()
+            self.grad_sync.master_stale = False
         expected = set(self._reference_key_order())
         missing = sorted(expected - set(state_dict.keys()))
         unexpected = sorted(set(state_dict.keys()) - expected)
@@ -436,7 +468,12 @@ class AVM(nn.Module):
         load_state_dict, in-place edits of the Parameter or of the arena) changes `_w5_version()` and the copy is re-made."""
         w5 = self._pflat("visbl.linear5.weight")
         if self.grad_sync is not None and self.grad_sync.master_stale and self._w5b_version != self._w5_version():
-            self.grad_sync.gather_master(self)           # the copy is invalid AND foreign slices of the master are stale
+            # the 16-bit copy is invalid (something wrote linear5.weight outside the fused step) AND the fp32 master of the other
+            # ranks' slices is stale: re-casting would bake stale weights in, and the remedy is a collective that this rank-local
+            # condition must not trigger on one rank alone (the others would not join it: deadlock)
+            raise GoalnetError("visbl.linear5.weight was written outside the fused step while the other ranks' slices of its fp32 master "
+                               "are stale (GradSync(shard_linear5=True), 16-bit mode): call model.grad_sync.consolidate(model) on every "
+                               "rank BEFORE editing / optimizer steps outside train_step")
         if self._w5b is None or self._w5b.numel() != w5.numel():
             self._w5b, self._w5b_version = torch.empty(w5.numel(), dtype=self._h16, device=self._device), None
         if self._w5b_version != self._w5_version():
@@ -452,8 +489,6 @@ class AVM(nn.Module):
     def _padbuf(self, key, n, h, w, c):
         """Cached zero-padded bf16 activation buffer (borders/guards zeroed once, interior rewritten every step)."""
         k = (key, n, h, w, c)
-        if not hasattr(self, "_padbufs"):
-            self._padbufs, self._padgen = {}, {}
         if k not in self._padbufs:
             self._padbufs[k] = ops.padded_bf16_alloc(n, h, w, c, self._device, dtype=self._h16)
         self._padgen[key] = self._padgen.get(key, 0) + 1      # backward checks that its saved operand was not overwritten
@@ -923,7 +958,12 @@ class AVM(nn.Module):
             ops.grad_finite_check(self._garena[after:], self._state[0], self._guard[0], self._guard[1])
             guard = self._guard[0]
         self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard, _done=done_early)
-        ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
+        if guard is not None:
+            # a step whose Adam was skipped is not counted (torch's GradScaler does not count it either): the retry runs under
+            # the same step count; `_adam_t` on the host counts ATTEMPTED steps
+            ops.counters_add4_guarded(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1], guard)
+        else:
+            ops.counters_add4(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1])
         return loss, out
 
     def _adam_segments(self):
@@ -938,9 +978,25 @@ class AVM(nn.Module):
         return [(0, s5.offset), (slo, shi), (after, self._arena_numel)]
 
     def _loss_scale_for(self, n: int) -> float:
-        if self.loss_scale is not None:
-            return float(self.loss_scale)
-        return float(2 ** (10 + max(0, math.ceil(math.log2(max(n, 1))))))
+        if self._loss_scale is not None:
+            return float(self._loss_scale) / (1 << self._loss_scale_backoff) if self._loss_scale_backoff else float(self._loss_scale)
+        return float(2.0 ** (10 + max(0, math.ceil(math.log2(max(n, 1)))) - self._loss_scale_backoff))
+
+    def overflow_skipped_steps(self) -> int:
+        """precision="fp16": optimizer steps skipped so far because a gradient overflowed (one host read-back)"""
+        return 0 if self._guard is None else int(self._guard[1].item())
+
+    def update_loss_scale(self) -> bool:
+        """precision="fp16": the loss scale is static inside a step (a captured graph bakes it in), so a persistent overflow
+        would skip every step silently. Call this where the host synchronises anyway (loop.VideoTrainer does, at its per-video
+        read-back): when steps were skipped since the last call the scale is halved (True is returned; graphs keyed on the old
+        scale are not replayed again). Skipped steps are not counted as optimizer steps (goalnet_counters_add4_guarded)."""
+        k = self.overflow_skipped_steps()
+        if k > self._skipped_seen:
+            self._skipped_seen = k
+            self._loss_scale_backoff += 1
+            return True
+        return False
 
     def _adam_state(self):
         segs = self._adam_segments()

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void cross_entropy_kernel(const float* __rest
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const float* r = s + (int64_t)n * C;
         int y = (int)(labels[n] - 1.f);                     // (labels - 1).long(): truncation toward zero
-        y = y < 0 ? 0 : (y >= C ? C - 1 : y);               // torch raises for classes outside [0, C); the host wrapper checks labels
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);               // torch raises for classes outside [0, C); here they are clamped (the labels are device memory: no host check)
         float mx = r[0];
         for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
         float sum = 0.f;

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, int64
 }
 
 // any non-finite value in g -> *bad_step = max(*bad_step, this step's 1-based count): the fused Adam of this step then returns
-// without touching anything (adam_kernel) and bumps nothing; no reset between steps is needed, any number of blocks may write
+// without touching anything (adam_kernel); any number of blocks may write. The step's last launch
+// (goalnet_counters_add4_guarded, stepstate.hip) keeps the step count where it is for a stamped step and clears the stamp.
 __global__ __launch_bounds__(256) void grad_finite_check_kernel(const float* __restrict__ g, int64_t n, const int64_t* __restrict__ step,
                                                                int64_t step_bias, int64_t* __restrict__ bad_step,
                                                                int64_t* __restrict__ skipped) {

@@ -18,6 +18,20 @@ __global__ void counters_add4_kernel(int64_t* ctr, int64_t d0, int64_t d1, int64
     ctr[i] += i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3;
 }
 
+// precision = "fp16": when goalnet_grad_finite_check stamped this step (*bad_step == the 1-based count this step ran under) the
+// fused Adam left everything untouched; the step count then does NOT advance either (torch's GradScaler does not count skipped
+// steps: the next step's bias corrections are those of the step that was skipped) and the stamp is cleared, so that the
+// retry — which runs under the same count — is not taken for the overflowed one. The other three counters always advance.
+__global__ void counters_add4_guarded_kernel(int64_t* ctr, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int64_t* bad_step) {
+    const int i = threadIdx.x;
+    if (i == 0) {
+        if (*bad_step == ctr[0] + d0) *bad_step = 0;
+        else ctr[0] += d0;
+    } else {
+        ctr[i] += i == 1 ? d1 : i == 2 ? d2 : d3;
+    }
+}
+
 struct RowCopies { goalnet_rowcopy seg[GOALNET_ROWCOPY_MAX]; };
 
 // several gathers / scatters in one launch: blockIdx.y selects the segment
@@ -77,6 +91,13 @@ int goalnet_counters_add4(int64_t* counters, int64_t d0, int64_t d1, int64_t d2,
     GN_REQUIRE(counters, GOALNET_E_NULL, "counters_add4: null pointer");
     hipLaunchKernelGGL(counters_add4_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, counters, d0, d1, d2, d3);
     GN_LAUNCH_CHECK("counters_add4");
+    return 0;
+}
+
+int goalnet_counters_add4_guarded(int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int64_t* bad_step, void* stream) {
+    GN_REQUIRE(counters && bad_step, GOALNET_E_NULL, "counters_add4_guarded: null pointer");
+    hipLaunchKernelGGL(counters_add4_guarded_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, counters, d0, d1, d2, d3, bad_step);
+    GN_LAUNCH_CHECK("counters_add4_guarded");
     return 0;
 }
 

@@ -22,7 +22,9 @@ its 1/world slice of linear5.weight only (its optimizer state exists only for th
 and 8 B/param of memory become 1/world of that), and the updated slices are all-gathered back into every rank's
 arena — asynchronously: the gather overlaps the next step's conv forward and is waited for right before linear5
 (`wait_weights`). With precision="bf16" the gather moves the bf16 GEMM copy of the weights (half the bytes); the fp32
-master of foreign slices is then stale until `gather_master()` (called by `AVM.state_dict()`; a collective).
+master of foreign slices is then stale until `consolidate()` — a collective every rank must call before `state_dict()`
+(which raises while slices are stale rather than communicating implicitly). EXPERIMENTAL: exercised on RCCL with one
+forced rank (tests/test_gpu_rccl.py) and on two gloo ranks, never yet on RCCL with more than one rank.
 
 Replica consistency: `sync_params()` (run automatically before the first synchronised step) broadcasts rank 0's
 parameters, BatchNorm buffers, optimizer state and dropout seed, so ranks that were constructed with different torch
@@ -108,24 +110,30 @@ class GradSync:
         if not dist.is_initialized() or self.world == 1:
             return
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
-        tensors = [model._arena]
+        # the tensor list below must be the SAME on every rank (a broadcast a rank does not join is a deadlock): "does the model
+        # carry optimizer state" is a per-rank fact, so rank 0's answer is broadcast first and every rank follows it
+        if model._state is None:
+            model._make_state()
+        meta = torch.tensor([model.dropout_seed, model._adam_t, model._drop_step] +
+                            [int(getattr(model.visbl, f"bnorm{i}").num_batches_tracked) for i in (1, 2, 3)] +
+                            [int(model._adam_m is not None and not self.sharded(model))],
+                            dtype=torch.int64, device=model._arena.device)
+        dist.broadcast(meta, src=src, group=self.group)
+        seed0, adam_t, drop_step, *nbt, has_opt = [int(v) for v in meta.tolist()]
+        tensors = [model._arena, model._state[0:2]]         # the device counters themselves: applied Adam steps, dropout draws
         for i in (1, 2, 3):
             bn = getattr(model.visbl, f"bnorm{i}")
             tensors += [bn.running_mean, bn.running_var]
-        if model._adam_m is not None and not self.sharded(model):
+        if has_opt:
+            model._adam_state()                             # a rank without moments allocates them, then receives rank 0's
             tensors += [model._adam_m, model._adam_v]
+        elif model._adam_m is not None and not self.sharded(model):
+            model._adam_m = model._adam_v = model._adam_segs = None        # rank 0 starts without optimizer state: so does this rank
         for t in tensors:
             dist.broadcast(t, src=src, group=self.group)
-        meta = torch.tensor([model.dropout_seed, model._adam_t, model._drop_step] +
-                            [int(getattr(model.visbl, f"bnorm{i}").num_batches_tracked) for i in (1, 2, 3)],
-                            dtype=torch.int64, device=model._arena.device)
-        dist.broadcast(meta, src=src, group=self.group)
-        seed0, adam_t, drop_step, *nbt = [int(v) for v in meta.tolist()]
         model._adam_t, model._drop_step = adam_t, drop_step
         for i, v in zip((1, 2, 3), nbt):
             getattr(model.visbl, f"bnorm{i}").num_batches_tracked.fill_(v)
-        if model._state is not None:
-            model._state[0:2].copy_(meta[1:3])
         # dropout: standard DDP = every rank an independent process -> an independent stream per rank, derived from rank 0's
         # seed; global-batch mode keeps ONE seed and draws this rank's rows of the global masks (AVM._masks)
         model.dropout_seed = seed0 if model.stat_sync is not None else (seed0 + _GOLDEN * self.rank) % (1 << 63)
@@ -198,6 +206,12 @@ class GradSync:
         if self._gather_work is not None:
             self._gather_work.wait()
             self._gather_work = None
+
+    def consolidate(self, model) -> None:
+        """Call on EVERY rank before `state_dict()`, before a stock optimizer / in-place edit touches linear5.weight, or before
+        switching the exchange mode: waits for the in-flight weight all-gather and (16-bit modes with shard_linear5) all-gathers
+        the fp32 master slices. A collective — `AVM.state_dict()` refuses to run while slices are stale instead of issuing it."""
+        self.gather_master(model)
 
     def gather_master(self, model) -> None:
         """bf16 + shard_linear5: bring the fp32 master of linear5.weight up to date on every rank (collective)."""

@@ -42,8 +42,8 @@ class VideoTrainer:
         self.subbatch_size = subbatch_size          # main.py:44
         self.lr, self.betas, self.eps = lr, betas, eps
         self.graphs = graphs
-        self._graphs: Dict[int, torch.cuda.CUDAGraph] = {}
-        self._uses_w5b: Dict[int, bool] = {}        # graph of size n reads the bf16 copy of linear5.weight (precision="bf16", n > 16)
+        self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}        # (sub-batch size, loss scale) -> graph
+        self._uses_w5b: Dict[tuple, bool] = {}      # that graph reads the bf16 copy of linear5.weight (precision="bf16", n > 16)
         self._seen = set()
         self._pool = None
         self._cap = 0                               # frames the staging tables hold
@@ -106,8 +106,9 @@ class VideoTrainer:
             self._sub_step(n)                       # collectives / supplied masks / per-kernel timing: eager
             self.eager_steps += 1
             return
-        g = self._graphs.get(n)
-        if g is not None and self._uses_w5b.get(n) and m._w5b_version != m._w5_version():
+        gkey = (n, m._loss_scale_for(n))                # the loss scale is a host scalar baked into the captured launches
+        g = self._graphs.get(gkey)
+        if g is not None and self._uses_w5b.get(gkey) and m._w5b_version != m._w5_version():
             # the captured graph reads the bf16 copy of linear5.weight and keeps it fresh through its own fused Adam, but holds
             # no cast node: a writer outside the graph since the last step (load_state_dict, a stock optimizer, an in-place
             # edit) has left the copy stale. One eager step re-casts it (AVM._w5_bf16) and re-validates the stamp.
@@ -115,8 +116,8 @@ class VideoTrainer:
             self.eager_steps += 1
             return
         if g is None:
-            if n not in self._seen:                 # first step of this size: eager (allocates Adam state, operand buffers)
-                self._seen.add(n)
+            if gkey not in self._seen:              # first step of this size: eager (allocates Adam state, operand buffers)
+                self._seen.add(gkey)
                 self._sub_step(n)
                 self.eager_steps += 1
                 return
@@ -133,8 +134,8 @@ class VideoTrainer:
             m._adam_t, m._drop_step, nbt, m.keep_ctx = saved
             for i, v in zip((1, 2, 3), nbt):
                 getattr(m.visbl, f"bnorm{i}").num_batches_tracked.fill_(v)
-            self._graphs[n] = g
-            self._uses_w5b[n] = m._w5b is not None and m._w5b_version == m._w5_version() and m.last_used_w5b
+            self._graphs[gkey] = g
+            self._uses_w5b[gkey] = m._w5b is not None and m._w5b_version == m._w5_version() and m.last_used_w5b
         g.replay()
         self._host_bookkeeping_after_replay()
         self.replays += 1
@@ -186,6 +187,10 @@ class VideoTrainer:
         if m._state is None:
             m._make_state()
         m._state[2:4].zero_()                       # subbatch_offset, iterations (main.py:173-175)
+        if m.precision == "fp16":
+            # the previous video's results have been read back by now (main.py:203): a cheap place to notice skipped steps and
+            # halve the loss scale (AVM.update_loss_scale) — a static scale would otherwise stall training silently
+            m.update_loss_scale()
         sb = self.subbatch_size
         subs = 0
         for off in range(0, n_frames, sb):

@@ -34,9 +34,16 @@ def _chk(*ts):
             raise _lib.GoalnetError(f"unexpected dtype {t.dtype}")
 
 
+def _req(cond, msg):
+    """argument / shape checks raise RuntimeError (what ATen raises for a shape mismatch in the reference, SURVEY.md §8(b)
+    "Ownership / errors"); unlike `assert` they survive `python -O`"""
+    if not cond:
+        raise RuntimeError(msg)
+
+
 def _ld(t):
     """leading dimension (row stride) of a 2-D view with unit column stride"""
-    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    _req(t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), "_ld: argument check failed: t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1)")
     return t.stride(0)
 
 
@@ -47,14 +54,14 @@ def lib():
 # ---------------------------------------------------------------------------------------------
 def fill_uniform(dst, seed, tensor_id, lo, hi):
     _chk(dst)
-    assert dst.is_contiguous() and dst.dtype == F32
+    _req(dst.is_contiguous() and dst.dtype == F32, "fill_uniform: argument check failed: dst.is_contiguous() and dst.dtype == F32")
     check(lib().goalnet_fill_uniform(dst.data_ptr(), dst.numel(), seed, tensor_id, lo, hi, _s()), "fill_uniform")
     return dst
 
 
 def dropout_mask(dst, seed, tensor_id, p):
     _chk(dst)
-    assert dst.is_contiguous() and dst.dtype == F32
+    _req(dst.is_contiguous() and dst.dtype == F32, "dropout_mask: argument check failed: dst.is_contiguous() and dst.dtype == F32")
     check(lib().goalnet_dropout_mask(dst.data_ptr(), dst.numel(), seed, tensor_id, p, _s()), "dropout_mask")
     return dst
 
@@ -62,23 +69,23 @@ def dropout_mask(dst, seed, tensor_id, p):
 def transpose_inner(src, dst, B, R, C):
     """[B][R][C] -> [B][C][R] on contiguous buffers"""
     _chk(src, dst)
-    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() == B * R * C
+    _req(src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() == B * R * C, "transpose_inner: argument check failed: src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() == B * R * C")
     check(lib().goalnet_transpose_inner(src.data_ptr(), dst.data_ptr(), B, R, C, _s()), "transpose_inner")
     return dst
 
 
 def conv3x3_weight_flip(w, wt, cout, cin):
     _chk(w, wt)
-    assert w.numel() == wt.numel() == cout * cin * 9
+    _req(w.numel() == wt.numel() == cout * cin * 9, "conv3x3_weight_flip: argument check failed: w.numel() == wt.numel() == cout * cin * 9")
     check(lib().goalnet_conv3x3_weight_flip(w.data_ptr(), wt.data_ptr(), cout, cin, _s()), "conv3x3_weight_flip")
     return wt
 
 
 def conv1_fwd(x_nchw, w, b, y, N, H, W):
     _chk(x_nchw, w, b, y)
-    assert x_nchw.is_contiguous() and x_nchw.numel() == N * 3 * H * W
+    _req(x_nchw.is_contiguous() and x_nchw.numel() == N * 3 * H * W, "conv1_fwd: argument check failed: x_nchw.is_contiguous() and x_nchw.numel() == N * 3 * H * W")
     Ho, Wo = (H + 3) // 3 + 1, (W + 3) // 3 + 1
-    assert y.numel() == N * Ho * Wo * 64 and w.numel() == 64 * 27 and b.numel() == 64
+    _req(y.numel() == N * Ho * Wo * 64 and w.numel() == 64 * 27 and b.numel() == 64, "conv1_fwd: argument check failed: y.numel() == N * Ho * Wo * 64 and w.numel() == 64 * 27 and b.numel() == 64")
     check(lib().goalnet_conv1_fwd(x_nchw.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, H, W, _s()), "conv1_fwd")
     return y
 
@@ -86,7 +93,7 @@ def conv1_fwd(x_nchw, w, b, y, N, H, W):
 def conv1_wgrad(x_nchw, dy, dw, db, N, H, W):
     _chk(x_nchw, dy, dw, db)
     Ho, Wo = (H + 3) // 3 + 1, (W + 3) // 3 + 1
-    assert dy.numel() == N * Ho * Wo * 64 and dw.numel() == 64 * 27 and db.numel() == 64
+    _req(dy.numel() == N * Ho * Wo * 64 and dw.numel() == 64 * 27 and db.numel() == 64, "conv1_wgrad: argument check failed: dy.numel() == N * Ho * Wo * 64 and dw.numel() == 64 * 27 and db.numel() == 64")
     nbytes = lib().goalnet_conv1_wgrad_ws_bytes(N, H, W)
     ws = torch.empty(nbytes // 4, dtype=F32, device=dy.device)
     check(lib().goalnet_conv1_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes,
@@ -100,9 +107,9 @@ def stat_parts(units):
 
 def _rows(partials, width):
     """the partial-sum kernels take the row count from the buffer the caller allocated: [nparts][width] doubles"""
-    assert partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() % width == 0
+    _req(partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() % width == 0, "_rows: argument check failed: partials.dtype == torch.float64 and partials.is_contiguous() and partials.numel() % width == 0")
     n = partials.numel() // width
-    assert 1 <= n <= STAT_PARTS, n
+    _req(1 <= n <= STAT_PARTS, "_rows: argument check failed: 1 <= n <= STAT_PARTS")
     return n
 
 
@@ -114,13 +121,13 @@ def idx_to_nhwc(idx, N, Hp, Wp, C):
 
 def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
     _chk(y, p, idx, partials)
-    assert y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C
-    assert idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())
+    _req(y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C, "pool_bnstats_fwd: argument check failed: y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C")
+    _req(idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel()), "pool_bnstats_fwd: argument check failed: idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel())")
     if p.dtype in H16:                              # pooled activation stored in 16 bits (statistics of the stored values)
         check(lib().goalnet_pool_bnstats_fwd_p16(y.data_ptr(), int(y.dtype in H16), p.data_ptr(), _p(idx), partials.data_ptr(),
                                                  _rows(partials, 2 * C), N, Hc, Wc, C, _f16(y, p), _s()), "pool_bnstats_fwd_p16")
         return
-    assert y.dtype == F32
+    _req(y.dtype == F32, "pool_bnstats_fwd: argument check failed: y.dtype == F32")
     check(lib().goalnet_pool_bnstats_fwd(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C),
                                          N, Hc, Wc, C, _s()), "pool_bnstats_fwd")
 
@@ -128,7 +135,7 @@ def pool_bnstats_fwd(y, p, idx, partials, N, Hc, Wc, C):
 def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mean, invstd, scale, shift):
     _chk(partials, gamma, beta, rmean, rvar, mean, invstd, scale, shift)
     for t in (gamma, beta, mean, invstd, scale, shift):
-        assert t.numel() == C and t.is_contiguous()
+        _req(t.numel() == C and t.is_contiguous(), "bn_finalize: argument check failed: t.numel() == C and t.is_contiguous()")
     check(lib().goalnet_bn_finalize(partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps,
                                     count, C, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _s()),
           "bn_finalize")
@@ -137,7 +144,7 @@ def bn_finalize(partials, gamma, beta, rmean, rvar, momentum, eps, count, C, mea
 def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
     """dz: fp32, or bf16 as the *_o16 GEMMs write it; p: fp32, or bf16 as pool_bnstats_fwd stores it into a bf16 tensor"""
     _chk(dz, p, mean, invstd, partials)
-    assert dz.numel() == p.numel() == npix * C
+    _req(dz.numel() == p.numel() == npix * C, "bn_bwd_reduce: argument check failed: dz.numel() == p.numel() == npix * C")
     if dz.dtype in H16 or p.dtype in H16:
         check(lib().goalnet_bn_bwd_reduce_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
                                             mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), _rows(partials, 2 * C), npix, C,
@@ -149,7 +156,7 @@ def bn_bwd_reduce(dz, p, mean, invstd, partials, npix, C):
 
 def bn_bwd_finalize(partials, gamma, mean, invstd, count, C, dgamma, dbeta, coef3):
     _chk(partials, gamma, mean, invstd, dgamma, dbeta, coef3)
-    assert coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C
+    _req(coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C, "bn_bwd_finalize: argument check failed: coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C")
     check(lib().goalnet_bn_bwd_finalize(partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), count, C,
                                         dgamma.data_ptr(), dbeta.data_ptr(), coef3.data_ptr(), _s()), "bn_bwd_finalize")
 
@@ -157,7 +164,7 @@ def bn_bwd_finalize(partials, gamma, mean, invstd, count, C, dgamma, dbeta, coef
 def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dbias_partials)
     npool = N * (Hc - 2) * (Wc - 2) * C
-    assert dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C
+    _req(dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C, "bnpool_bwd: argument check failed: dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C")
     if dz.dtype in H16 or p.dtype in H16:
         check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
                                                idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), None, dbias_partials.data_ptr(),
@@ -169,7 +176,7 @@ def bnpool_bwd(dz, p, idx, coef3, dy, dbias_partials, N, Hc, Wc, C):
 
 def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C):
     _chk(dz, p, idx, coef3, dy, dypad, dbias_partials)
-    assert dypad.dtype in H16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C
+    _req(dypad.dtype in H16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C, "bnpool_bwd_bf16p: argument check failed: dypad.dtype in H16 and dypad.numel() >= N * (Hc + 2) * (Wc + 2) * C")
     if dz.dtype in H16 or p.dtype in H16:
         check(lib().goalnet_bnpool_bwd_bf16p_t(dz.data_ptr(), int(dz.dtype in H16), p.data_ptr(), int(p.dtype in H16),
                                                idx.data_ptr(), coef3.data_ptr(), _p(dy), dypad.data_ptr(), dbias_partials.data_ptr(),
@@ -182,22 +189,22 @@ def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C)
 
 def partials_sum(partials, nparts, stride, C, out):
     _chk(partials, out)
-    assert partials.dtype == torch.float64 and out.numel() == C
+    _req(partials.dtype == torch.float64 and out.numel() == C, "partials_sum: argument check failed: partials.dtype == torch.float64 and out.numel() == C")
     check(lib().goalnet_partials_sum(partials.data_ptr(), nparts, stride, C, out.data_ptr(), _s()), "partials_sum")
 
 
 def partials_sum_f64(partials, C, out):
     """out[c] (double) = sum over the rows of partials[rows][C]"""
     _chk(partials, out)
-    assert partials.dtype == torch.float64 and out.dtype == torch.float64 and out.numel() == C
+    _req(partials.dtype == torch.float64 and out.dtype == torch.float64 and out.numel() == C, "partials_sum_f64: argument check failed: partials.dtype == torch.float64 and out.dtype == torch.float64 and out.numel() == C")
     check(lib().goalnet_partials_sum_f64(partials.data_ptr(), _rows(partials, C), C, C, out.data_ptr(), _s()), "partials_sum_f64")
 
 
 def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(x, scale, shift, w, bias, y)
-    assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
-    assert scale is None or (scale.numel() == Cin and shift.numel() == Cin)
-    assert bias is None or bias.numel() == Cout
+    _req(x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin, "conv3x3_fwd: argument check failed: x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin")
+    _req(scale is None or (scale.numel() == Cin and shift.numel() == Cin), "conv3x3_fwd: argument check failed: scale is None or (scale.numel() == Cin and shift.numel() == Cin)")
+    _req(bias is None or bias.numel() == Cout, "conv3x3_fwd: argument check failed: bias is None or bias.numel() == Cout")
     nbytes = lib().goalnet_conv3x3_fwd_ws_bytes(N, H, W, Cin, Cout)       # > 0 only for small N (split-K slabs)
     ws = torch.empty(nbytes // 4, dtype=F32, device=x.device) if nbytes else None
     check(lib().goalnet_conv3x3_fwd(x.data_ptr(), _p(scale), _p(shift), w.data_ptr(), _p(bias), int(relu), y.data_ptr(),
@@ -207,7 +214,7 @@ def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
 
 def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
     _chk(x, scale, shift, dy, dw)
-    assert x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin
+    _req(x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin, "conv3x3_wgrad: argument check failed: x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin")
     nbytes = lib().goalnet_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=x.device)
     check(lib().goalnet_conv3x3_wgrad(x.data_ptr(), _p(scale), _p(shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
@@ -223,27 +230,27 @@ H16 = (BF16, F16)          # the 16-bit storage formats of the reduced-precision
 def _f16(*ts):
     """the `f16` flag of a call: 1 when its 16-bit tensors are torch.float16, 0 for bfloat16 (they must agree)"""
     kinds = {t.dtype for t in ts if t is not None and t.dtype in H16}
-    assert len(kinds) <= 1, "16-bit operands of one call must share a format"
+    _req(len(kinds) <= 1, "_f16: 16-bit operands of one call must share a format")
     return int(F16 in kinds)
 
 
 def cast_bf16(x, y):
     _chk(x, y)
-    assert x.dtype == F32 and y.dtype in H16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _req(x.dtype == F32 and y.dtype in H16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel(), "cast_bf16: argument check failed: x.dtype == F32 and y.dtype in H16 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()")
     check(lib().goalnet_cast_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _f16(y), _s()), "cast_bf16")
     return y
 
 
 def cast_f32(x, y):
     _chk(x, y)
-    assert x.dtype in H16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _req(x.dtype in H16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel(), "cast_f32: argument check failed: x.dtype in H16 and y.dtype == F32 and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()")
     check(lib().goalnet_cast_f32(x.data_ptr(), y.data_ptr(), x.numel(), _f16(x), _s()), "cast_f32")
     return y
 
 
 def bn_apply_bf16(x, scale, shift, y, C):
     _chk(x, scale, shift, y)
-    assert x.dtype in (F32,) + H16 and y.dtype in H16 and x.numel() == y.numel() and scale.numel() == C
+    _req(x.dtype in (F32,) + H16 and y.dtype in H16 and x.numel() == y.numel() and scale.numel() == C, "bn_apply_bf16: argument check failed: x.dtype in (F32,) + H16 and y.dtype in H16 and x.numel() == y.numel() and scale.numel() == C")
     if x.dtype in H16:
         check(lib().goalnet_bn_apply_bf16_p16(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel(), C, _f16(x, y), _s()), "bn_apply_bf16_p16")
         return y
@@ -253,8 +260,8 @@ def bn_apply_bf16(x, scale, shift, y, C):
 
 def conv3x3_fwd_bf16(x, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(x, w, bias, y)
-    assert x.dtype in H16 and w.dtype == x.dtype and y.dtype == F32
-    assert x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    _req(x.dtype in H16 and w.dtype == x.dtype and y.dtype == F32, "conv3x3_fwd_bf16: argument check failed: x.dtype in H16 and w.dtype == x.dtype and y.dtype == F32")
+    _req(x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin, "conv3x3_fwd_bf16: argument check failed: x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin")
     check(lib().goalnet_conv3x3_fwd_bf16(x.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _f16(x, w), _s()),
           "conv3x3_fwd_bf16")
     return y
@@ -271,7 +278,7 @@ def padded_bf16_alloc(N, H, W, C, device, dtype=torch.bfloat16):
 
 def to_bf16_padded(x, scale, shift, ypad, N, H, W, C):
     _chk(x, scale, shift, ypad)
-    assert x.dtype in (F32,) + H16 and ypad.dtype in H16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C
+    _req(x.dtype in (F32,) + H16 and ypad.dtype in H16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C, "to_bf16_padded: argument check failed: x.dtype in (F32,) + H16 and ypad.dtype in H16 and x.numel() == N * H * W * C and ypad.numel() >= N * (H + 2) * (W + 2) * C")
     if x.dtype in H16:
         check(lib().goalnet_to_bf16_padded_p16(x.data_ptr(), _p(scale), _p(shift), ypad.data_ptr(), N, H, W, C, _f16(x, ypad), _s()), "to_bf16_padded_p16")
         return ypad
@@ -281,8 +288,8 @@ def to_bf16_padded(x, scale, shift, ypad, N, H, W, C):
 
 def conv3x3_fwd_bf16p(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(xpad, w, bias, y)
-    assert xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == F32
-    assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    _req(xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == F32, "conv3x3_fwd_bf16p: argument check failed: xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == F32")
+    _req(y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin, "conv3x3_fwd_bf16p: argument check failed: y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin")
     nbytes = lib().goalnet_conv3x3_fwd_bf16p_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=y.device) if nbytes else None
     check(lib().goalnet_conv3x3_fwd_bf16p(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout,
@@ -297,8 +304,8 @@ def conv3x3_fwd_bf16p_o16_ok(N, H, W, Cin, Cout) -> bool:
 def conv3x3_fwd_bf16p_o16(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
     """bf16 result (bias None, relu False: the data gradient); only for dims conv3x3_fwd_bf16p_o16_ok accepts"""
     _chk(xpad, w, bias, y)
-    assert xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == xpad.dtype
-    assert y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin
+    _req(xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == xpad.dtype, "conv3x3_fwd_bf16p_o16: argument check failed: xpad.dtype in H16 and w.dtype == xpad.dtype and y.dtype == xpad.dtype")
+    _req(y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin, "conv3x3_fwd_bf16p_o16: argument check failed: y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin")
     check(lib().goalnet_conv3x3_fwd_bf16p_o16(xpad.data_ptr(), w.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout,
                                               _f16(xpad, w, y), _s()),
           "conv3x3_fwd_bf16p_o16")
@@ -307,7 +314,7 @@ def conv3x3_fwd_bf16p_o16(xpad, w, bias, relu, y, N, H, W, Cin, Cout):
 
 def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
     _chk(xpad, dypad, dw)
-    assert xpad.dtype in H16 and dypad.dtype == xpad.dtype and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin
+    _req(xpad.dtype in H16 and dypad.dtype == xpad.dtype and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin, "conv3x3_wgrad_bf16: argument check failed: xpad.dtype in H16 and dypad.dtype == xpad.dtype and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin")
     nbytes = lib().goalnet_conv3x3_wgrad_bf16_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
     check(lib().goalnet_conv3x3_wgrad_bf16(xpad.data_ptr(), dypad.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
@@ -317,10 +324,10 @@ def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
 
 def linear_bwd_dx_bf16(dy, w, dx, mult=None):
     _chk(dy, w, dx, mult)
-    assert dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32
+    _req(dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32, "linear_bwd_dx_bf16: argument check failed: dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32")
     M, J = dy.shape
     K = dx.shape[1]
-    assert w.numel() == J * K and dx.shape[0] == M
+    _req(w.numel() == J * K and dx.shape[0] == M, "linear_bwd_dx_bf16: argument check failed: w.numel() == J * K and dx.shape[0] == M")
     check(lib().goalnet_linear_bwd_dx_bf16(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
                                            dx.data_ptr(), _ld(dx), M, K, J, _f16(dy, w), _s()), "linear_bwd_dx_bf16")
     return dx
@@ -333,10 +340,10 @@ def linear_bwd_dx_bf16_o16_ok(M, K, J) -> bool:
 def linear_bwd_dx_bf16_o16(dy, w, dx):
     """bf16 result; only for dims linear_bwd_dx_bf16_o16_ok accepts"""
     _chk(dy, w, dx)
-    assert dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == dy.dtype
+    _req(dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == dy.dtype, "linear_bwd_dx_bf16_o16: argument check failed: dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == dy.dtype")
     M, J = dy.shape
     K = dx.shape[1]
-    assert w.numel() == J * K and dx.shape[0] == M
+    _req(w.numel() == J * K and dx.shape[0] == M, "linear_bwd_dx_bf16_o16: argument check failed: w.numel() == J * K and dx.shape[0] == M")
     check(lib().goalnet_linear_bwd_dx_bf16_o16(dy.data_ptr(), _ld(dy), w.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _f16(dy, w, dx), _s()),
           "linear_bwd_dx_bf16_o16")
     return dx
@@ -344,20 +351,20 @@ def linear_bwd_dx_bf16_o16(dy, w, dx):
 
 def linear_bwd_dw_bf16(dy, x, dw):
     _chk(dy, x, dw)
-    assert dy.dtype in H16 and x.dtype == dy.dtype and dw.dtype == F32
+    _req(dy.dtype in H16 and x.dtype == dy.dtype and dw.dtype == F32, "linear_bwd_dw_bf16: argument check failed: dy.dtype in H16 and x.dtype == dy.dtype and dw.dtype == F32")
     M, J = dy.shape
     K = x.shape[1]
-    assert dw.numel() == J * K and x.shape[0] == M
+    _req(dw.numel() == J * K and x.shape[0] == M, "linear_bwd_dw_bf16: argument check failed: dw.numel() == J * K and x.shape[0] == M")
     check(lib().goalnet_linear_bwd_dw_bf16(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), dw.data_ptr(), M, K, J, _f16(dy, x), _s()), "linear_bwd_dw_bf16")
     return dw
 
 
 def linear_fwd_bf16(x, w, bias, y, *, relu=False, dropmask=None, mult_out=None):
     _chk(x, w, bias, y, dropmask, mult_out)
-    assert x.dtype in H16 and w.dtype == x.dtype
+    _req(x.dtype in H16 and w.dtype == x.dtype, "linear_fwd_bf16: argument check failed: x.dtype in H16 and w.dtype == x.dtype")
     M, K = x.shape
     J = y.shape[1]
-    assert w.numel() == J * K and y.shape[0] == M
+    _req(w.numel() == J * K and y.shape[0] == M, "linear_fwd_bf16: argument check failed: w.numel() == J * K and y.shape[0] == M")
     nbytes = lib().goalnet_linear_fwd_bf16_ws_bytes(M, K, J)
     ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=x.device) if nbytes else None
     check(lib().goalnet_linear_fwd_bf16(x.data_ptr(), _ld(x), w.data_ptr(), _p(bias), int(relu), _p(dropmask),
@@ -373,7 +380,7 @@ def linear_fwd(x, w, bias, y, *, relu=False, scale=None, shift=None, bnC=0, drop
     M = x.shape[0]
     K = x.shape[1] if K is None else K
     J = y.shape[1]
-    assert w.numel() == J * K and y.shape[0] == M
+    _req(w.numel() == J * K and y.shape[0] == M, "linear_fwd: argument check failed: w.numel() == J * K and y.shape[0] == M")
     nbytes = lib().goalnet_linear_fwd_ws_bytes(M, K, J)
     ws = torch.empty(max(nbytes // 4, 1), dtype=F32, device=x.device) if nbytes else None
     check(lib().goalnet_linear_fwd(x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, w.data_ptr(), _p(bias), int(relu),
@@ -387,7 +394,7 @@ def linear_bwd_dx(dy, w, dx, mult=None):
     _chk(dy, w, dx, mult)
     M, J = dy.shape
     K = dx.shape[1]
-    assert w.numel() == J * K and dx.shape[0] == M
+    _req(w.numel() == J * K and dx.shape[0] == M, "linear_bwd_dx: argument check failed: w.numel() == J * K and dx.shape[0] == M")
     check(lib().goalnet_linear_bwd_dx(dy.data_ptr(), _ld(dy), w.data_ptr(), _p(mult), 0 if mult is None else _ld(mult),
                                       dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx")
     return dx
@@ -398,7 +405,7 @@ def linear_bwd_dw(dy, x, dw, *, scale=None, shift=None, bnC=0, db=None):
     _chk(dy, x, dw, scale, shift, db)
     M, J = dy.shape
     K = x.shape[1]
-    assert dw.numel() == J * K and x.shape[0] == M and (db is None or db.numel() == J)
+    _req(dw.numel() == J * K and x.shape[0] == M and (db is None or db.numel() == J), "linear_bwd_dw: argument check failed: dw.numel() == J * K and x.shape[0] == M and (db is None or db.numel() == J)")
     check(lib().goalnet_linear_bwd_dw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), _p(scale), _p(shift), bnC, dw.data_ptr(), _p(db),
                                       M, K, J, _s()), "linear_bwd_dw")
     return dw
@@ -407,7 +414,7 @@ def linear_bwd_dw(dy, x, dw, *, scale=None, shift=None, bnC=0, db=None):
 def colsum(x, out):
     _chk(x, out)
     M, J = x.shape
-    assert out.numel() == J
+    _req(out.numel() == J, "colsum: argument check failed: out.numel() == J")
     check(lib().goalnet_colsum(x.data_ptr(), _ld(x), M, J, out.data_ptr(), _s()), "colsum")
     return out
 
@@ -422,7 +429,7 @@ def mul(x, m, y):
 def conv1d_fwd(x, w, b, y, relu, N, Cin, L, Cout, stride=2, pad=1):
     _chk(x, w, b, y)
     Lo = (L + 2 * pad - 3) // stride + 1
-    assert x.numel() == N * Cin * L and y.numel() == N * Cout * Lo and w.numel() == Cout * Cin * 3
+    _req(x.numel() == N * Cin * L and y.numel() == N * Cout * Lo and w.numel() == Cout * Cin * 3, "conv1d_fwd: argument check failed: x.numel() == N * Cin * L and y.numel() == N * Cout * Lo and w.numel() == Cout * Cin * 3")
     check(lib().goalnet_conv1d_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), int(relu), y.data_ptr(), N, Cin, L, Cout, stride, pad,
                                    _s()), "conv1d_fwd")
     return y
@@ -431,7 +438,7 @@ def conv1d_fwd(x, w, b, y, relu, N, Cin, L, Cout, stride=2, pad=1):
 def conv1d_bwd(x, dz, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
     _chk(x, dz, w, dx, dw, db)
     Lo = (L + 2 * pad - 3) // stride + 1
-    assert x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo
+    _req(x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo, "conv1d_bwd: argument check failed: x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo")
     nbytes = lib().goalnet_conv1d_bwd_ws_bytes(N, Cin, Cout)
     ws = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device) if nbytes else None
     check(lib().goalnet_conv1d_bwd(x.data_ptr(), dz.data_ptr(), w.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(), N, Cin, L, Cout,
@@ -440,7 +447,7 @@ def conv1d_bwd(x, dz, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
 
 def relu_bwd(dy, y, dz):
     _chk(dy, y, dz)
-    assert dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel()
+    _req(dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel(), "relu_bwd: argument check failed: dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel()")
     check(lib().goalnet_relu_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _s()), "relu_bwd")
     return dz
 
@@ -454,7 +461,7 @@ def head_fwd(h, w, b, logit, out):
 def head_bwd(dout, out, h, w, mult, dh, dw, db):
     _chk(dout, out, h, w, mult, dh, dw, db)
     N, K = h.shape
-    assert dout.numel() == N and out.numel() == N and dout.is_contiguous() and out.is_contiguous()
+    _req(dout.numel() == N and out.numel() == N and dout.is_contiguous() and out.is_contiguous(), "head_bwd: argument check failed: dout.numel() == N and out.numel() == N and dout.is_contiguous() and out.is_contiguous()")
     check(lib().goalnet_head_bwd(dout.data_ptr(), out.data_ptr(), h.data_ptr(), _ld(h), w.data_ptr(), _p(mult),
                                  0 if mult is None else _ld(mult), dh.data_ptr(), _ld(dh), dw.data_ptr(), db.data_ptr(), N, K, _s()),
           "head_bwd")
@@ -465,7 +472,7 @@ def cls_head_fwd(h, w, b, logits, scores):
     _chk(h, w, b, logits, scores)
     N, K = h.shape
     C = scores.shape[1]
-    assert w.numel() == C * K and b.numel() == C and scores.is_contiguous() and (logits is None or logits.is_contiguous())
+    _req(w.numel() == C * K and b.numel() == C and scores.is_contiguous() and (logits is None or logits.is_contiguous()), "cls_head_fwd: argument check failed: w.numel() == C * K and b.numel() == C and scores.is_contiguous() and (logits is None or logits.is_contiguous())")
     check(lib().goalnet_cls_head_fwd(h.data_ptr(), _ld(h), w.data_ptr(), b.data_ptr(), _p(logits), scores.data_ptr(), N, K, C, _s()), "cls_head_fwd")
 
 
@@ -473,7 +480,7 @@ def cross_entropy(scores, labels, loss, dscores):
     """nn.CrossEntropyLoss()(scores, (labels - 1).long()) and its gradient wrt scores"""
     _chk(scores, labels, loss, dscores)
     N, C = scores.shape
-    assert labels.numel() == N and scores.is_contiguous() and (dscores is None or dscores.is_contiguous())
+    _req(labels.numel() == N and scores.is_contiguous() and (dscores is None or dscores.is_contiguous()), "cross_entropy: argument check failed: labels.numel() == N and scores.is_contiguous() and (dscores is None or dscores.is_contiguous())")
     check(lib().goalnet_cross_entropy(scores.data_ptr(), labels.data_ptr(), _p(loss), _p(dscores), N, C, _s()), "cross_entropy")
 
 
@@ -481,7 +488,7 @@ def cls_head_bwd(dscores, scores, h, w, mult, dh, dw, db):
     _chk(dscores, scores, h, w, mult, dh, dw, db)
     N, K = h.shape
     C = scores.shape[1]
-    assert dscores.is_contiguous() and scores.is_contiguous() and dw.numel() == C * K and db.numel() == C
+    _req(dscores.is_contiguous() and scores.is_contiguous() and dw.numel() == C * K and db.numel() == C, "cls_head_bwd: argument check failed: dscores.is_contiguous() and scores.is_contiguous() and dw.numel() == C * K and db.numel() == C")
     check(lib().goalnet_cls_head_bwd(dscores.data_ptr(), scores.data_ptr(), h.data_ptr(), _ld(h), w.data_ptr(), _p(mult),
                                      0 if mult is None else _ld(mult), dh.data_ptr(), _ld(dh), dw.data_ptr(), db.data_ptr(), N, K, C, _s()),
           "cls_head_bwd")
@@ -490,7 +497,7 @@ def cls_head_bwd(dscores, scores, h, w, mult, dh, dw, db):
 def argmax_plus1(scores, classes):
     _chk(scores, classes)
     N, C = scores.shape
-    assert classes.numel() == N and scores.is_contiguous()
+    _req(classes.numel() == N and scores.is_contiguous(), "argmax_plus1: argument check failed: classes.numel() == N and scores.is_contiguous()")
     check(lib().goalnet_argmax_plus1(scores.data_ptr(), classes.data_ptr(), N, C, _s()), "argmax_plus1")
     return classes
 
@@ -498,14 +505,14 @@ def argmax_plus1(scores, classes):
 def mse_bcast(pred, labels, loss, dpred):
     _chk(pred, labels, loss, dpred)
     N = pred.numel()
-    assert labels.numel() == N
+    _req(labels.numel() == N, "mse_bcast: argument check failed: labels.numel() == N")
     check(lib().goalnet_mse_bcast(pred.data_ptr(), labels.data_ptr(), N, _p(loss), _p(dpred), _s()), "mse_bcast")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _chk(p, g, m, v)
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n
+    _req(g.numel() == n and m.numel() == n and v.numel() == n, "adam_step: argument check failed: g.numel() == n and m.numel() == n and v.numel() == n")
     check(lib().goalnet_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, step, grad_scale,
                                   _s()), "adam_step")
 
@@ -515,7 +522,7 @@ I64 = torch.int64
 
 
 def _ctr(t):
-    assert t.is_cuda and t.dtype == I64 and t.numel() == 1
+    _req(t.is_cuda and t.dtype == I64 and t.numel() == 1, "_ctr: argument check failed: t.is_cuda and t.dtype == I64 and t.numel() == 1")
     return t.data_ptr()
 
 
@@ -528,7 +535,7 @@ def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p, row_o
     [row_offset, row_offset + n) of the (row_offset + n, width) masks the same stream yields (data-parallel shards)."""
     _chk(dst)
     total = n * sum(widths)
-    assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() == total
+    _req(dst.is_contiguous() and dst.dtype == F32 and dst.numel() == total, "dropout_masks_dev: argument check failed: dst.is_contiguous() and dst.dtype == F32 and dst.numel() == total")
     arr = (ctypes.c_int * len(widths))(*widths)
     check(lib().goalnet_dropout_masks_dev(dst.data_ptr(), n, arr, len(widths), seed, tid_base, tid_stride, _ctr(step), p, int(row_offset), _s()),
           "dropout_masks_dev")
@@ -540,15 +547,21 @@ def dropout_masks_dev(dst, n, widths, seed, tid_base, tid_stride, step, p, row_o
 
 
 def counters_add4(counters, d0, d1, d2, d3):
-    assert counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous()
+    _req(counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous(), "counters_add4: argument check failed: counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous()")
     check(lib().goalnet_counters_add4(counters.data_ptr(), int(d0), int(d1), int(d2), int(d3), _s()), "counters_add4")
+
+
+def counters_add4_guarded(counters, d0, d1, d2, d3, bad_step):
+    """counters_add4 of a precision="fp16" step: the step count stays where it is when this step's Adam was skipped"""
+    _req(counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous(), "counters_add4_guarded: argument check failed: counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous()")
+    check(lib().goalnet_counters_add4_guarded(counters.data_ptr(), int(d0), int(d1), int(d2), int(d3), _ctr(bad_step), _s()), "counters_add4_guarded")
 
 
 def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_bias=0):
     """Adam with the 1-based step count = *step + step_bias"""
     _chk(p, g, m, v)
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n
+    _req(g.numel() == n and m.numel() == n and v.numel() == n, "adam_step_dev: argument check failed: g.numel() == n and m.numel() == n and v.numel() == n")
     check(lib().goalnet_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
                                       int(step_bias), grad_scale, _s()), "adam_step_dev")
 
@@ -557,7 +570,7 @@ def adam_step_dev_shadow(p, g, m, v, lr, beta1, beta2, eps, step, shadow, shadow
     """adam_step_dev that also writes bf16(p_new) of arena[shadow_begin : shadow_begin + shadow.numel()] into `shadow`"""
     _chk(p, g, m, v, shadow)
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype in H16 and shadow.is_contiguous()
+    _req(g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype in H16 and shadow.is_contiguous(), "adam_step_dev_shadow: argument check failed: g.numel() == n and m.numel() == n and v.numel() == n and shadow.dtype in H16 and shadow.is_contiguous()")
     check(lib().goalnet_adam_step_dev_shadow(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
                                              int(step_bias), grad_scale, shadow.data_ptr(), int(shadow_begin), shadow.numel(), _f16(shadow), _s()),
           "adam_step_dev_shadow")
@@ -567,7 +580,7 @@ def adam_step_dev_guarded(p, g, m, v, lr, beta1, beta2, eps, step, bad_step, sha
     """precision="fp16": adam_step_dev[_shadow] that leaves everything untouched when grad_finite_check stamped this step"""
     _chk(p, g, m, v, shadow)
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or (shadow.dtype in H16 and shadow.is_contiguous()))
+    _req(g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or (shadow.dtype in H16 and shadow.is_contiguous())), "adam_step_dev_guarded: argument check failed: g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or (shadow.dtype in H16 and shadow.is_contiguous()))")
     check(lib().goalnet_adam_step_dev_guarded(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
                                               int(step_bias), grad_scale, _p(shadow), int(shadow_begin), 0 if shadow is None else shadow.numel(),
                                               0 if shadow is None else _f16(shadow), _ctr(bad_step), _s()), "adam_step_dev_guarded")
@@ -575,14 +588,14 @@ def adam_step_dev_guarded(p, g, m, v, lr, beta1, beta2, eps, step, bad_step, sha
 
 def scale_(x, s):
     _chk(x)
-    assert x.dtype == F32 and x.is_contiguous()
+    _req(x.dtype == F32 and x.is_contiguous(), "scale_: argument check failed: x.dtype == F32 and x.is_contiguous()")
     check(lib().goalnet_scale(x.data_ptr(), x.numel(), float(s), _s()), "scale")
     return x
 
 
 def grad_finite_check(g, step, bad_step, skipped, step_bias=1):
     _chk(g)
-    assert g.dtype == F32 and g.is_contiguous()
+    _req(g.dtype == F32 and g.is_contiguous(), "grad_finite_check: argument check failed: g.dtype == F32 and g.is_contiguous()")
     check(lib().goalnet_grad_finite_check(g.data_ptr(), g.numel(), _ctr(step), int(step_bias), _ctr(bad_step), _ctr(skipped), _s()), "grad_finite_check")
 
 
@@ -592,9 +605,9 @@ def rows_copy_batch(segments):
     arr = (_lib.RowCopy * len(segments))()
     for k, (table, block, nrows, cursor, bias, gather) in enumerate(segments):
         _chk(table, block)
-        assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+        _req(table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype, "rows_copy_batch: argument check failed: table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype")
         row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
-        assert block.numel() * block.element_size() == row_bytes * nrows
+        _req(block.numel() * block.element_size() == row_bytes * nrows, "rows_copy_batch: argument check failed: block.numel() * block.element_size() == row_bytes * nrows")
         src, dst = (table, block) if gather else (block, table)
         arr[k] = _lib.RowCopy(src.data_ptr(), dst.data_ptr(), row_bytes, nrows, 1 if gather else 0, _ctr(cursor), int(bias))
     check(lib().goalnet_rows_copy_batch(arr, len(segments), _s()), "rows_copy_batch")
@@ -603,16 +616,16 @@ def rows_copy_batch(segments):
 def rows_gather(table, block, nrows, cursor):
     """block[0:nrows] = table[cursor : cursor + nrows]; rows are the leading dimension of contiguous tensors."""
     _chk(table, block)
-    assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+    _req(table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype, "rows_gather: argument check failed: table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype")
     row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
-    assert block.numel() * block.element_size() == row_bytes * nrows
+    _req(block.numel() * block.element_size() == row_bytes * nrows, "rows_gather: argument check failed: block.numel() * block.element_size() == row_bytes * nrows")
     check(lib().goalnet_rows_gather(table.data_ptr(), block.data_ptr(), row_bytes, nrows, _ctr(cursor), _s()), "rows_gather")
 
 
 def rows_scatter(block, table, nrows, cursor):
     """table[cursor : cursor + nrows] = block[0:nrows]"""
     _chk(table, block)
-    assert table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype
+    _req(table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype, "rows_scatter: argument check failed: table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype")
     row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
-    assert block.numel() * block.element_size() == row_bytes * nrows
+    _req(block.numel() * block.element_size() == row_bytes * nrows, "rows_scatter: argument check failed: block.numel() * block.element_size() == row_bytes * nrows")
     check(lib().goalnet_rows_scatter(block.data_ptr(), table.data_ptr(), row_bytes, nrows, _ctr(cursor), _s()), "rows_scatter")

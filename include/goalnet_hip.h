@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GOALNET_ABI_VERSION 1
+#define GOALNET_ABI_VERSION 2
 
 #define GOALNET_OK 0
 #define GOALNET_E_NULL (-1)      /* required pointer is NULL */
@@ -303,6 +303,10 @@ int goalnet_grad_finite_check(const float* g, int64_t n, const int64_t* step, in
 int goalnet_adam_step_dev_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                                   double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* shadow_16 /* nullable */,
                                   int64_t shadow_begin, int64_t shadow_count, int f16, const int64_t* bad_step, void* stream);
+/* goalnet_counters_add4 for a guarded step: when *bad_step == counters[0] + d0 (this step was stamped and its Adam skipped) the
+ * step count does not advance — a skipped step is not counted, as with torch's GradScaler — and the stamp is cleared so that the
+ * retry under the same count is judged on its own gradients; counters 1..3 advance as usual. */
+int goalnet_counters_add4_guarded(int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int64_t* bad_step, void* stream);
 /* block[0:nrows] = table[*cursor : *cursor + nrows]  (batch_frames[a:b], main.py:181-184); row_bytes % 4 == 0 */
 int goalnet_rows_gather(const void* table, void* block, int64_t row_bytes, int nrows, const int64_t* cursor, void* stream);
 /* table[*cursor : *cursor + nrows] = block[0:nrows]  (predictions.extend(...), losses.append(...), main.py:195-196) */

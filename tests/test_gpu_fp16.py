@@ -211,9 +211,57 @@ def test_fp16_overflow_guard_skips_the_update_and_counts_it():
     model.loss_scale = 2.0 ** 60                                          # every 16-bit activation gradient overflows
     model.train_step(aud, vis, lab)
     torch.cuda.synchronize()
-    assert model._guard[1].item() == 1 and model._guard[0].item() == 2    # step 2 stamped, one update skipped
+    # one update skipped; the stamp (step 2) was consumed by the step's last launch and the step count did NOT advance: a skipped
+    # step is not an optimizer step (torch's GradScaler semantics) — the retry runs under the bias corrections of step 2
+    assert model._guard[1].item() == 1 and model._guard[0].item() == 0 and model._state[0].item() == 1
+    assert model.overflow_skipped_steps() == 1
     assert torch.equal(model._arena, good) and torch.equal(model._adam_m, m1), "a skipped step must leave parameters and moments untouched"
-    model.loss_scale = None                                               # back to the automatic scale
+    # the static scale would overflow again and again: the check a caller makes where it synchronises anyway halves it
+    assert model.update_loss_scale() and model._loss_scale_for(n) == 2.0 ** 59 and not model.update_loss_scale()
+    model.train_step(aud, vis, lab)                                       # still far too large: skipped again, still step 2
+    torch.cuda.synchronize()
+    assert model._guard[1].item() == 2 and model._state[0].item() == 1 and torch.equal(model._arena, good)
+    model.loss_scale = None                                               # back to the automatic scale (backoff cleared)
+    assert model._loss_scale_for(n) == 2.0 ** 15
     model.train_step(aud, vis, lab)
     torch.cuda.synchronize()
-    assert model._guard[1].item() == 1 and not torch.equal(model._arena, good) and torch.isfinite(model._arena).all()
+    assert model._guard[1].item() == 2 and model._state[0].item() == 2
+    assert not torch.equal(model._arena, good) and torch.isfinite(model._arena).all()
+
+
+def test_precision_setter_switches_format_loss_scale_and_cached_operands():
+    """`m.precision = "fp16"` on a model that has stepped in bf16 must behave like a model constructed in fp16 —
+    the automatic loss scale (bf16 runs with 1.0; binary16 activation gradients would flush to zero with it), no cached
+    bfloat16 operand buffers handed to the fp16 kernels, a fresh 16-bit copy of linear5.weight."""
+    n, h = 20, 40
+    params = synth.make_params(h, h, 30, True)
+    vis = torch.from_numpy(synth.make_visual(n, h, h)).to(DEV); aud = torch.from_numpy(synth.make_audio(n)).to(DEV)
+    lab = torch.from_numpy(synth.make_labels(n)).to(DEV)
+    masks = [torch.from_numpy(m) for m in synth.make_drop_masks(n, step=0)]
+    fresh = _fp16_model(h, params)
+    fresh.set_dropout_masks(masks)
+    fresh.train_step(aud, vis, lab)
+    m = AVM(audio_included=True, device=DEV, precision="bf16", seed=synth.BASE_SEED)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd.update(avm_ref.init_buffers())
+    m.load_state_dict(sd)
+    m.set_dropout_masks(masks)
+    assert m.loss_scale == 1.0
+    m.train_step(aud, vis, lab)                                           # a bf16 step: caches bfloat16 operand buffers and the copy
+    assert m._padbufs and m._w5b is not None and m._w5b.dtype == torch.bfloat16
+    m.load_state_dict(sd)
+    m._adam_m.zero_(); m._adam_v.zero_(); m._state.zero_(); m._adam_t = 0
+    m.precision = "fp16"
+    assert m.loss_scale is None and not m._padbufs and m._w5b is None
+    m.train_step(aud, vis, lab)
+    torch.cuda.synchronize()
+    assert m._arena_grad_scale == fresh._arena_grad_scale == 2.0 ** 15
+    assert torch.equal(m._garena, fresh._garena) and torch.equal(m._arena, fresh._arena), "setter-switched model != fresh fp16 model"
+    assert m._guard.tolist() == [0, 0]
+    # an explicit scale survives a switch; None restores the automatic one
+    m.loss_scale = 256.0
+    m.precision = "bf16"
+    assert m.loss_scale == 256.0
+    m.loss_scale = None
+    m.precision = "bf16"
+    assert m.loss_scale == 1.0

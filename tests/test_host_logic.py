@@ -164,6 +164,10 @@ class _FakeReplica:
     def _w5_version(self):
         return (self._arena._version, self._load_count)
 
+    def _adam_state(self):
+        if self._adam_m is None:
+            self._adam_m, self._adam_v = torch.zeros(self._arena_numel), torch.zeros(self._arena_numel)
+
 
 def _sync_worker(rank, world, port, tmp):
     import torch.distributed as dist
@@ -207,6 +211,14 @@ def _sync_worker(rank, world, port, tmp):
     sync.gather_master(fake)
     out["bf16"] = {"shadow": fake._w5b.clone(), "stale": stale, "master": fake._arena[lo:hi].clone(),
                    "stamp_ok": fake._w5b_version == fake._w5_version(), "still_stale": sync.master_stale}
+    # ---- optimizer state present on one rank only (a per-rank fact: e.g. one rank resumed): rank 0's answer decides the
+    # broadcast list on every rank — a list that differed between ranks would deadlock
+    for owner in (0, 1):
+        f2 = _FakeReplica(specs, m._arena_numel, rank)
+        if rank == owner:
+            f2._adam_m, f2._adam_v = torch.full((m._arena_numel,), 0.5), torch.full((m._arena_numel,), 0.25)
+        GradSync().sync_params(f2)
+        out[f"opt_owner{owner}"] = None if f2._adam_m is None else (float(f2._adam_m[7]), float(f2._adam_v[7]))
     torch.save(out, os.path.join(tmp, f"y{rank}.pt"))
     dist.destroy_process_group()
 
@@ -238,4 +250,7 @@ def test_param_sync_and_sharded_linear5_world2_gloo(tmp_path):
         assert torch.equal(x["shadow"], r[0]["bf16"]["shadow"]) and torch.equal(x["master"], r[0]["bf16"]["master"])
         assert torch.equal(x["shadow"], x["master"].to(torch.bfloat16)) and x["stamp_ok"] and not x["still_stale"]
         assert not torch.equal(x["stale"], x["master"])                 # the foreign slice really was out of date
+    for k in (0, 1):
+        assert r[k]["opt_owner0"] == (0.5, 0.25), "rank 0's Adam moments must reach a rank that had none"
+        assert r[k]["opt_owner1"] is None, "rank 0 has no optimizer state: a rank that had some starts without it too"
     assert shard_bounds(0, 1000, 8, 3) is None and shard_bounds(64, 64 + 8 * 128, 8, 3) == (64 + 3 * 128, 64 + 4 * 128)
