@@ -45,14 +45,19 @@ PROTOTYPES = {
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_pool_bn_fwd_fused": (c_int, [P, P, P, P, c_int, P, P, P, P, c_float, c_float, c_int64, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bn_bwd_reduce_fused": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P]),
+    "goalnet_bnpool_bwd_fused": (c_int, [P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_int, P]),
     "goalnet_conv3x3_fwd_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_fwd_bf16p_kernel_name": (c_char_p, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_wgrad_codes_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "goalnet_conv3x3_wgrad_codes": (c_int, [P, c_int, c_int, c_int, P]),
+    "goalnet_conv3x3_wgrad": (c_int, [P, P, P, P, P, P, c_size_t, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_cast_bf16": (c_int, [P, P, c_int64, c_int, P]),
     "goalnet_cast_f32": (c_int, [P, P, c_int64, c_int, P]),
     "goalnet_bn_apply_bf16": (c_int, [P, P, P, P, c_int64, c_int, c_int, P]),

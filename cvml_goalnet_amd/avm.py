@@ -536,6 +536,11 @@ class AVM(nn.Module):
         pooled activation the fused backward can read back"""
         return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536 and AVM._bwd16_ok(wc)
 
+    def _small_bn(self, a, b, n, hc, wc, c):
+        """the one-launch pool / BatchNorm kernels (csrc/pool_bn.hip, goalnet_*_fused): fp32 tensors, local statistics, few elements"""
+        return (a.dtype == F32 and b.dtype == F32 and self.stat_sync is None and n * hc * wc * c <= ops.SMALL_BN_ELEMS
+                and os.environ.get("GOALNET_SMALL_BN", "1") != "0")
+
     def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
         """maxpool + BN statistics of block i on conv output y (N,hc,wc,c). Returns (p, idx, mean, invstd, scale, shift).
         p16: the pooled activation is stored as bf16 (precision="bf16", blocks whose every consumer is a bf16 GEMM pass)."""
@@ -543,12 +548,19 @@ class AVM(nn.Module):
         assert p16 or y.dtype == F32
         p = torch.empty(n, hc - 2, wc - 2, c, dtype=self._h16 if p16 else F32, device=dev)
         idx = torch.empty(n, hc - 2, wc - 2, c, dtype=torch.uint8, device=dev) if save else None
-        # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
-        partials = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=dev)
-        ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
         bn = getattr(self.visbl, f"bnorm{i}")
         st = torch.empty(4, c, dtype=F32, device=dev)
         count = n * (hc - 2) * (wc - 2)
+        if self._small_bn(y, p, n, hc, wc, c):
+            # the reference's operating point (10 frames of 40 x 40): pool, statistics AND the finalise step in one launch
+            partials = torch.empty(ops.stat_parts(max(8 * n, min(count * c // 1024, 256))) * 2 * c, dtype=torch.float64, device=dev)
+            ops.pool_bn_fwd_fused(y, p, idx, partials, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
+                                  bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, count, st, n, hc, wc, c)
+            bn.num_batches_tracked += 1
+            return p, idx, st
+        # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
+        partials = torch.empty(ops.stat_parts(8 * n) * 2 * c, dtype=torch.float64, device=dev)
+        ops.pool_bnstats_fwd(y, p, idx, partials, n, hc, wc, c)
         if self.stat_sync is not None:
             partials, count = self._global_sums(partials, 2 * c), count * self.stat_sync.world
         ops.bn_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
@@ -692,9 +704,19 @@ class AVM(nn.Module):
         G = self._gflat
         p, idx, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"st{i}"]
         npix = n * (hc - 2) * (wc - 2)
+        coef3 = torch.empty(3 * c, dtype=F32, device=dev)
+        small = self._small_bn(dbn, p, n, hc, wc, c) and not (self._half and i > 1)
+        if small:
+            # the reference's operating point: reduce + finalise in one launch, then the fused backward + bias gradient in one
+            partials = torch.empty(ops.stat_parts(max(npix // 64, min(npix * c // 1024, 128))) * 2 * c, dtype=torch.float64, device=dev)
+            ops.bn_bwd_reduce_fused(dbn, p, st[0], st[1], partials, npix, c, self._pflat(f"visbl.bnorm{i}.weight"), npix,
+                                    G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
+            dparts = torch.empty(ops.stat_parts(max(8 * n, min(n * hc * wc * c // 1024, 256))) * c, dtype=torch.float64, device=dev)
+            dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
+            ops.bnpool_bwd_fused(dbn, p, idx, coef3, dy, dparts, G(f"visbl.conv{i}.bias"), n, hc, wc, c)
+            return dy
         partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
         ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, npix, c)
-        coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
                             G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
         if self.stat_sync is not None:

@@ -24,6 +24,11 @@ struct EpiP {
     void* out16;                          // non-null (256^2 bf16 kernel, raw epilogue only): the result as bf16 [rows][ld] instead of `out`
     // splitk_reduce only (fp32 conv weight gradient): out[row][col] -= corr_sh[col % corr_C] * corr_u[row * 9 + col / corr_C]
     const float* corr_u; const float* corr_sh; int corr_C;
+    // fused split-K reduction (fp32 engine, few output tiles: the reference's 10-frame sub-batches): the raw partial sums go to
+    // slabs + split * slab_stride (ld = cols), every block then takes a ticket on tile_ctr[tile] and the LAST block of a tile
+    // sums the tile's slabs in split order (the order of splitk_reduce_kernel: same bits) and applies this epilogue (out, ld,
+    // bias, relu, mul, mult_out) — no second launch. tile_ctr[] must be zero on entry and is zero again on exit.
+    float* slabs; int* tile_ctr;
 };
 
 __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {
@@ -43,8 +48,9 @@ __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, 
 template <bool AIL, bool BIL>
 __device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2][2], int tm, int tn, int split,
                                           int wm, int wn, int r, int h) {
-    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    float* outp = ep.slab_stride > 0 ? (ep.slabs ? ep.slabs : ep.out) + (int64_t)split * ep.slab_stride : ep.out;
     const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+    const int64_t ld = (ep.slab_stride > 0 && ep.slabs) ? (int64_t)ep.cols : ep.ld;
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
@@ -58,7 +64,7 @@ __device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2]
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e];
+                    if (colok && row < ep.rows) outp[row * ld + col] = acc[fm][fn][e];
                 }
             } else if (mode == EPI_BIAS_RELU) {
                 const float bv = ep.bias ? ep.bias[colc] : 0.f;
@@ -66,7 +72,7 @@ __device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2]
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = fmaxf(acc[fm][fn][e] + bv, lo);
+                    if (colok && row < ep.rows) outp[row * ld + col] = fmaxf(acc[fm][fn][e] + bv, lo);
                 }
             } else if (mode == EPI_MUL) {
                 float mv[16];
@@ -78,16 +84,63 @@ __device__ __forceinline__ void store_acc(const EpiP& ep, const f32x16 (&acc)[2]
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = acc[fm][fn][e] * mv[e];
+                    if (colok && row < ep.rows) outp[row * ld + col] = acc[fm][fn][e] * mv[e];
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + RS * ((e & 3) + 8 * (e >> 2));
-                    if (colok && row < ep.rows) outp[row * ep.ld + col] = epi_apply(ep, acc[fm][fn][e], row, col);
+                    if (colok && row < ep.rows) outp[row * ld + col] = epi_apply(ep, acc[fm][fn][e], row, col);
                 }
             }
         }
+}
+
+// The fused split-K reduction (EpiP::tile_ctr): called by every block of a split-K GEMM after its raw slab store. Release
+// (the block's slab stores reach device scope: L2 write-back on the multi-XCD part), ticket, and for the last block of the
+// tile acquire + sum + epilogue. TN = tile width (128 or 64), tiles are 128 rows.
+template <int TN>
+__device__ __forceinline__ void fused_splitk_reduce(const EpiP& ep, int tm, int tn, int tile_id, int nsplit, int tid) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int old = atomicAdd(&ep.tile_ctr[tile_id], 1);
+        s_last = old == nsplit - 1;
+        if (s_last) ep.tile_ctr[tile_id] = 0;              // nobody else touches this counter any more in this launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    constexpr int C4 = TN / 4, RP = 256 / C4;
+    const int col = tn * TN + (tid % C4) * 4;
+    if (col >= ep.cols) return;
+    for (int rl = tid / C4; rl < GEMM_BM; rl += RP) {
+        const int64_t row = (int64_t)tm * GEMM_BM + rl;
+        if (row >= ep.rows) break;
+        const float* s = ep.slabs + row * ep.cols + col;
+        float4 a = *reinterpret_cast<const float4*>(s);
+        int k = 1;
+        for (; k + 3 < nsplit; k += 4) {                     // four loads in flight, added in split order
+            const float4 b0 = *reinterpret_cast<const float4*>(s + (int64_t)k * ep.slab_stride);
+            const float4 b1 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 1) * ep.slab_stride);
+            const float4 b2 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 2) * ep.slab_stride);
+            const float4 b3 = *reinterpret_cast<const float4*>(s + (int64_t)(k + 3) * ep.slab_stride);
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        }
+        for (; k < nsplit; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(s + (int64_t)k * ep.slab_stride);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float* o = ep.out + row * ep.ld + col;
+        o[0] = epi_apply(ep, a.x, row, col);
+        o[1] = epi_apply(ep, a.y, row, col + 1);
+        o[2] = epi_apply(ep, a.z, row, col + 2);
+        o[3] = epi_apply(ep, a.w, row, col + 3);
+    }
 }
 
 // 4 x 4 transpose inside each quad of lanes: on entry register k of lane l holds element (row k, column l) of the quad's

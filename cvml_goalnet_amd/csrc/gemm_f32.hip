@@ -484,8 +484,9 @@ __device__ __forceinline__ void compute_tile_n64(const float* la, const float* l
 
 // epilogue of the 128 x 64 tile: D[row][col], col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ void store_acc_n64(const EpiP& ep, const f32x16 (&acc)[2], int tm, int tn, int split, int wave, int r, int h) {
-    float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    float* outp = ep.slab_stride > 0 ? (ep.slabs ? ep.slabs : ep.out) + (int64_t)split * ep.slab_stride : ep.out;
     const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
+    const int64_t ld = (ep.slab_stride > 0 && ep.slabs) ? (int64_t)ep.cols : ep.ld;
 #pragma unroll
     for (int fn = 0; fn < 2; ++fn) {
         const int col = tn * 64 + fn * 32 + r;
@@ -498,9 +499,9 @@ __device__ __forceinline__ void store_acc_n64(const EpiP& ep, const f32x16 (&acc
             const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
             if (!(colok && row < ep.rows)) continue;
             const float v = acc[fn][e];
-            if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
-            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v + bv, lo);
-            else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
+            if (mode == EPI_RAW) outp[row * ld + col] = v;
+            else if (mode == EPI_BIAS_RELU) outp[row * ld + col] = fmaxf(v + bv, lo);
+            else outp[row * ld + col] = epi_apply(ep, v, row, col);
         }
     }
 }
@@ -598,6 +599,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? (N64 ? 4 : AL::ONE_STAGE_BLOCKS)
     }
     if constexpr (N64) store_acc_n64(ep, acc[0], tm, tn, split, wave, r, h);
     else store_acc<!AL::KC, !BL::KC>(ep, acc, tm, tn, split, wm, wn, r, h);
+    if (ep.tile_ctr) {                                       // fused split-K reduction: the tile's last block sums the slabs
+        const int nsp = (ktiles + ktiles_per_split - 1) / ktiles_per_split;
+        fused_splitk_reduce<N64 ? 64 : BN>(ep, tm, tn, tm * tiles_n + tn, nsp, tid);
+    }
 }
 
 // sums `nsplit` raw slabs (deterministic order) and applies the epilogue. cols % 4 == 0.
@@ -671,6 +676,7 @@ int launch_gemm(const char* name, const typename AL::P& ap, const typename BL::P
     GN_REQUIRE(tiles_m * tiles_n < (1ll << 31), GOALNET_E_SHAPE, "%s: too many tiles", name);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
+    GN_REQUIRE(!ep.tile_ctr || (ktiles + kps - 1) / kps == nsplit, GOALNET_E_SHAPE, "%s: fused split-K needs every split non-empty", name);
     // >= 8 splits whose tiles fit an XCD's 64 resident blocks a few times over: XCD-local order (see the kernel)
     const bool xcd_local = nsplit >= 8 && tiles_m * tiles_n <= 256 && tiles_m * tiles_n * ((nsplit + 7) / 8 * 8) < (1ll << 31);
     dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, 1);
@@ -747,7 +753,7 @@ size_t goalnet_conv3x3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
 
 int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, const float* w,
                         const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        void* ws, size_t ws_bytes, int* tile_ctr, int n_ctr, void* stream) {
     GN_REQUIRE(x && w && y, GOALNET_E_NULL, "conv3x3_fwd: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "conv3x3_fwd: scale/shift must both be set or both NULL");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd: non-positive dim");
@@ -769,8 +775,14 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
                    "conv3x3_fwd: workspace too small or misaligned");
         ep = EpiP{EPI_RAW, (float*)ws, Cout, (int)M, Cout, nullptr, 0, nullptr, 0, nullptr, 0, M * Cout};
     }
-    int rc;
     const bool narrow = Cout <= 64 && !getenv("GOALNET_F32_N64_OFF");       // 128 x 64 tile (conv2's data gradient: 256 -> 64 channels)
+    // the caller lent zeroed ticket counters, one per output tile: the last block of each tile reduces (no second launch)
+    const bool fused = nsplit > 1 && tile_ctr && (int64_t)n_ctr >= ((M + BM - 1) / BM) * ((Cout + (narrow ? 64 : BN) - 1) / (narrow ? 64 : BN));
+    if (fused) {
+        ep = efinal;
+        ep.slabs = (float*)ws; ep.slab_stride = M * Cout; ep.tile_ctr = tile_ctr;
+    }
+    int rc;
     if (scale) {
         ConvALoader<true>::P ap{x, H, W, Cin, M, scale, shift};
         rc = narrow ? launch_gemm<ConvALoader<true>, KCLoader<false>, true>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st)
@@ -780,7 +792,7 @@ int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, 
         rc = narrow ? launch_gemm<ConvALoader<false>, KCLoader<false>, true>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st)
                     : launch_gemm<ConvALoader<false>, KCLoader<false>>("conv3x3_fwd", ap, bp, ep, M, Cout, ktiles, nsplit, 0, st);
     }
-    if (rc || nsplit == 1) return rc;
+    if (rc || nsplit == 1 || fused) return rc;
     return launch_splitk_reduce("conv3x3_fwd.reduce", (const float*)ws, nsplit, M * Cout, efinal, st);
 }
 
@@ -840,8 +852,23 @@ size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     return wgrad_codes_bytes(M) + wgrad_border_bytes(N, Cout) + (size_t)wgrad_splits(M, Cin, Cout) * (size_t)Cout * 9 * Cin * sizeof(float);
 }
 
+int goalnet_conv3x3_wgrad_codes(uint32_t* codes, int N, int H, int W, void* stream) {
+    GN_REQUIRE(codes && N > 0 && H > 0 && W > 0, GOALNET_E_NULL, "conv3x3_wgrad_codes: bad arguments");
+    const int64_t M = (int64_t)N * H * W;
+    GN_REQUIRE(M < (1ll << 31) - 256, GOALNET_E_SHAPE, "conv3x3_wgrad_codes: N*H*W too large");
+    const int Mpad = (int)((M + 31) / 32 * 32);
+    int blocks = (Mpad / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(border_codes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, codes, (int)M, Mpad, H, W);
+    GN_LAUNCH_CHECK("conv3x3_wgrad_codes");
+    return 0;
+}
+
+size_t goalnet_conv3x3_wgrad_codes_bytes(int N, int H, int W) { return wgrad_codes_bytes((int64_t)N * H * W); }
+
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
-                          void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream) {
+                          void* ws, size_t ws_bytes, const uint32_t* codes_in, int* tile_ctr, int n_ctr,
+                          int N, int H, int W, int Cin, int Cout, void* stream) {
     GN_REQUIRE(x && dy && dw && ws, GOALNET_E_NULL, "conv3x3_wgrad: null pointer");
     GN_REQUIRE((scale == nullptr) == (shift == nullptr), GOALNET_E_NULL, "conv3x3_wgrad: scale/shift must both be set or both NULL");
     GN_REQUIRE(N > 0 && H > 0 && W > 0, GOALNET_E_SHAPE, "conv3x3_wgrad: non-positive dim");
@@ -862,7 +889,9 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     // few frames: data select in the loop, no correction pass (GOALNET_WGRAD_PATH=select|correct forces one: tests, A/B runs)
     const char* force = getenv("GOALNET_WGRAD_PATH");
     const bool dsel = force && force[0] == 's' ? true : force && force[0] == 'c' ? false : (int64_t)N * (H > W ? H : W) <= 4096;
-    {
+    if (codes_in) {
+        codes = const_cast<uint32_t*>(codes_in);      // the caller's table (goalnet_conv3x3_wgrad_codes: depends on N, H, W only)
+    } else {
         const int Mpad = (int)((M + 31) / 32 * 32);
         int blocks = (Mpad / 4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
@@ -877,6 +906,13 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
     }
     MCLoader<false>::P ap{dy, Cout, Cout, (int)M, nullptr, nullptr, 1};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
+    // few frames (no rank-one correction to apply): with ticket counters lent by the caller the last block of each tile reduces
+    const bool fused = nsplit > 1 && tile_ctr && (dsel || !scale) &&
+                       (int64_t)n_ctr >= (int64_t)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
+    if (fused) {
+        ep = EpiP{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, slab};
+        ep.slabs = slabs; ep.tile_ctr = tile_ctr;
+    }
     int rc;
     if (scale && dsel) {
         ConvWgradBLoader<true, true>::P bp{x, H, W, Cin, (int)M, scale, shift, codes};
@@ -888,7 +924,7 @@ int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift
         ConvWgradBLoader<false>::P bp{x, H, W, Cin, (int)M, nullptr, nullptr, codes};
         rc = launch_gemm<MCLoader<false>, ConvWgradBLoader<false>>("conv3x3_wgrad", ap, bp, ep, Cout, 9 * Cin, ktiles, nsplit, 1, st);
     }
-    if (rc) return rc;
+    if (rc || fused) return rc;
     EpiP er{EPI_RAW, dw, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     if (scale && !dsel) { er.corr_u = bu; er.corr_sh = shift; er.corr_C = Cin; }
     return launch_splitk_reduce("conv3x3_wgrad.reduce", slabs, nsplit, slab, er, st);

@@ -86,10 +86,90 @@ __device__ __forceinline__ double column_sum16(const double* __restrict__ col0, 
     return t;
 }
 
+// column_sum16's summation tree walked by ONE thread (same bits): the fused small-shape kernels below finalise inside the
+// producing launch, where a single block (the last to arrive) owns all C columns
+__device__ __forceinline__ double column_sum16_serial(const double* __restrict__ col0, int nparts, int64_t stride) {
+    double t = 0.0;
+    for (int pg = 0; pg < 16; ++pg) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int pt = pg;
+        for (; pt + 48 < nparts; pt += 64) {
+            a0 += col0[(int64_t)pt * stride];
+            a1 += col0[(int64_t)(pt + 16) * stride];
+            a2 += col0[(int64_t)(pt + 32) * stride];
+            a3 += col0[(int64_t)(pt + 48) * stride];
+        }
+        for (; pt < nparts; pt += 16) a0 += col0[(int64_t)pt * stride];
+        t += (a0 + a1) + (a2 + a3);
+    }
+    return t;
+}
+
+// Ticket for "the last block finalises": every block calls it after its partial row is written. Release (the row reaches
+// device scope: L2 write-back on the multi-XCD part), ticket, and for the last block an acquire. The counter must be zero on
+// entry and is zero again on exit (the same contract as EpiP::tile_ctr, gemm_common.h). Returns true in the last block.
+__device__ __forceinline__ bool last_block_ticket(int* ctr, int nblocks) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(ctr, 1);
+        s_last = old == nblocks - 1;
+        if (s_last) *ctr = 0;
+    }
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) __threadfence();
+    return last;
+}
+
+// what the small-shape kernels append to their launch (ctr == nullptr: nothing, the separate finalise kernels run)
+struct BnFin {          // forward: goalnet_bn_finalize's arguments
+    int* ctr; const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps; double count;
+    float* mean; float* invstd; float* scale; float* shift;
+};
+struct BnBwdFin {       // backward reduce: goalnet_bn_bwd_finalize's arguments (mean / invstd are the kernel's own)
+    int* ctr; const float* gamma; double count; float* dgamma; float* dbeta; float* coef3;
+};
+struct DbiasFin { int* ctr; float* dbias; };       // fused backward: goalnet_partials_sum of the conv bias gradient
+
+__device__ __forceinline__ void bn_finalize_one(int c, double s, double q, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                                float momentum, float eps, double count, float* mean, float* invstd, float* scale, float* shift) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = fm;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - fm * sc;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__device__ __forceinline__ void bn_bwd_finalize_one(int c, int C, double s, double q, const float* gamma, const float* mean, const float* invstd,
+                                                    double count, float* dgamma, float* dbeta, float* coef3) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
+    const double a = (double)gamma[c] * (double)invstd[c];
+    const double m1 = s / count, m2 = q / count;
+    const double b = -a * m2 * (double)invstd[c];
+    const double cc = -a * m1 - b * (double)mean[c];
+    coef3[c] = (float)a;
+    coef3[C + c] = (float)b;
+    coef3[2 * C + c] = (float)cc;
+}
+
 // max_pool2d CPU kernel), partial sums of p and p*p per channel.
 __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __restrict__ y, float* __restrict__ p,
                                                               uint8_t* __restrict__ idx, double* __restrict__ partials,
-                                                              int N, int Hc, int Wc, int C) {
+                                                              int N, int Hc, int Wc, int C, BnFin fin) {
     __shared__ double smem[256 * 8];
     const int tid = threadIdx.x;
     const int G = C >> 2;                 // channel groups of 4; G divides 256
@@ -127,6 +207,13 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __re
         acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
     }
     block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
+    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
+        for (int c = tid; c < C; c += 256) {
+            const double s = column_sum16_serial(partials + c, gridDim.x, 2 * C);
+            const double q = column_sum16_serial(partials + C + c, gridDim.x, 2 * C);
+            bn_finalize_one(c, s, q, fin.gamma, fin.beta, fin.rmean, fin.rvar, fin.momentum, fin.eps, fin.count, fin.mean, fin.invstd, fin.scale, fin.shift);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
@@ -139,21 +226,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     const double s = column_sum16(partials + c, nparts, 2 * C, c < C, sm);
     const double q = column_sum16(partials + C + c, nparts, 2 * C, c < C, sm);
     if (c >= C || threadIdx.x >= 16) return;
-    const double m = s / count;
-    double var = q / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const float fm = (float)m;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    mean[c] = fm;
-    invstd[c] = is;
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - fm * sc;
-    if (rmean) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    }
+    bn_finalize_one(c, s, q, gamma, beta, rmean, rvar, momentum, eps, count, mean, invstd, scale, shift);
 }
 
 // dz (the gradient wrt the BatchNorm output) arrives as fp32 or, from the bf16 GEMMs' bf16-output epilogue, as bf16
@@ -184,7 +257,7 @@ __device__ __forceinline__ float4 dz4_of(const h16raw& r) { return f4_of_h16(r.u
 template <typename DZ, typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           double* __restrict__ partials, int64_t npix, int C) {
+                                                           double* __restrict__ partials, int64_t npix, int C, BnBwdFin fin) {
     __shared__ double smem[256 * 8];
     const int tid = threadIdx.x;
     const int G = C >> 2;
@@ -202,6 +275,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict
         acc[0][3] += (double)d.w; acc[1][3] += (double)d.w * (double)((x.w - mu.w) * is.w);
     }
     block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
+    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
+        for (int c = tid; c < C; c += 256) {
+            const double s = column_sum16_serial(partials + c, gridDim.x, 2 * C);
+            const double q = column_sum16_serial(partials + C + c, gridDim.x, 2 * C);
+            bn_bwd_finalize_one(c, C, s, q, fin.gamma, mean, invstd, fin.count, fin.dgamma, fin.dbeta, fin.coef3);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
@@ -213,16 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const double s = column_sum16(partials + c, nparts, 2 * C, c < C, sm);
     const double q = column_sum16(partials + C + c, nparts, 2 * C, c < C, sm);
     if (c >= C || threadIdx.x >= 16) return;
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
-    // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
-    const double a = (double)gamma[c] * (double)invstd[c];
-    const double m1 = s / count, m2 = q / count;
-    const double b = -a * m2 * (double)invstd[c];
-    const double cc = -a * m1 - b * (double)mean[c];
-    coef3[c] = (float)a;
-    coef3[C + c] = (float)b;
-    coef3[2 * C + c] = (float)cc;
+    bn_bwd_finalize_one(c, C, s, q, gamma, mean, invstd, count, dgamma, dbeta, coef3);
 }
 
 // ---- backward phase 3: dy[n,h,w,c] = relu'(y) * sum over the (<= 9) pooling windows that contain (h,w) and
@@ -230,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ p,
                                                         const uint8_t* __restrict__ idx,
                                                         const float* __restrict__ coef3, float* __restrict__ dy,
-                                                        double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
+                                                        double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C, DbiasFin fin) {
     __shared__ double smem[256 * 4];
     const int tid = threadIdx.x;
     const int G = C >> 2;
@@ -269,6 +340,9 @@ __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict
         accb[0][0] += (double)acc.x; accb[0][1] += (double)acc.y; accb[0][2] += (double)acc.z; accb[0][3] += (double)acc.w;
     }
     block_reduce_store<1>(accb, G, tid, smem, dbias_partials + (int64_t)blockIdx.x * C, C, C);
+    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
+        for (int c = tid; c < C; c += 256) fin.dbias[c] = (float)column_sum16_serial(dbias_partials + c, gridDim.x, C);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,7 +917,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
         launch_pool_fwd_v2<float, float>(nparts, need, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     } else {
-        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
+        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C, BnFin{});
     }
     GN_LAUNCH_CHECK("pool_bnstats_fwd");
     return 0;
@@ -895,7 +969,7 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
     GN_PARTS_OK("bn_bwd_reduce");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C, BnBwdFin{});
     GN_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
@@ -911,13 +985,13 @@ int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf
     hipStream_t st = (hipStream_t)stream;
     typedef __hip_bfloat16 bf;
     typedef _Float16 hf;
-    if (f16 && dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, hf>), grid, block, 0, st, (const hf*)dz, (const hf*)p, mean, invstd, partials, npix, C);
-    else if (f16 && dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, float>), grid, block, 0, st, (const hf*)dz, (const float*)p, mean, invstd, partials, npix, C);
-    else if (f16 && p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, hf>), grid, block, 0, st, (const float*)dz, (const hf*)p, mean, invstd, partials, npix, C);
-    else if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C);
-    else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C);
-    else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C);
-    else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    if (f16 && dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, hf>), grid, block, 0, st, (const hf*)dz, (const hf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else if (f16 && dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, float>), grid, block, 0, st, (const hf*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else if (f16 && p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, hf>), grid, block, 0, st, (const float*)dz, (const hf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
     GN_LAUNCH_CHECK("bn_bwd_reduce_t");
     return 0;
 }
@@ -946,7 +1020,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
         launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
-                           dbias_partials, N, Hc, Wc, C);
+                           dbias_partials, N, Hc, Wc, C, DbiasFin{});
     }
     GN_LAUNCH_CHECK("bnpool_bwd");
     return 0;
@@ -994,6 +1068,52 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
     else if (p_bf16)       launch_bnpool_bwd_v2<float, bf>(nparts, need, st, (const float*)dz, (const bf*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
     else                   launch_bnpool_bwd_v2<float, float>(nparts, need, st, (const float*)dz, (const float*)p, idx, coef3, dy, dp, dbias_partials, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("bnpool_bwd_bf16p_t");
+    return 0;
+}
+
+/* ---- small shapes (the reference's 10-frame sub-batches at 40 x 40, main.py:177-196): the direct kernels with the finalise
+ * step folded in — the last block to arrive sums the partial rows in goalnet_bn_finalize's order and writes what the separate
+ * finalise launch would (same bits), so each BatchNorm / pool pass is ONE launch. ctr: one int32, zero on entry, zero on exit. */
+int goalnet_pool_bn_fwd_fused(const float* y, float* p, uint8_t* idx, double* partials, int nparts, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int64_t count,
+                              float* mean, float* invstd, float* scale, float* shift, int* ctr,
+                              int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(y && p && partials && gamma && beta && mean && invstd && scale && shift && ctr, GOALNET_E_NULL, "pool_bn_fwd_fused: null pointer");
+    GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "pool_bn_fwd_fused: running stats must both be set or both NULL");
+    GN_PARTS_OK("pool_bn_fwd_fused");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && count > 0, GOALNET_E_SHAPE, "pool_bn_fwd_fused: need Hc, Wc >= 3");
+    GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bn_fwd_fused: C=%d must be 4*2^k, <= 1024", C);
+    GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
+               "pool_bn_fwd_fused: pointers must be 16-byte aligned");
+    const BnFin fin{ctr, gamma, beta, running_mean, running_var, momentum, eps, (double)count, mean, invstd, scale, shift};
+    hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C, fin);
+    GN_LAUNCH_CHECK("pool_bn_fwd_fused");
+    return 0;
+}
+
+int goalnet_bn_bwd_reduce_fused(const float* dz, const float* p, const float* mean, const float* invstd, double* partials, int nparts,
+                                int64_t npix, int C, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* coef3,
+                                int* ctr, void* stream) {
+    GN_REQUIRE(dz && p && mean && invstd && partials && gamma && dgamma && dbeta && coef3 && ctr, GOALNET_E_NULL, "bn_bwd_reduce_fused: null pointer");
+    GN_REQUIRE(npix > 0 && count > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_fused: bad dims");
+    GN_PARTS_OK("bn_bwd_reduce_fused");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce_fused: alignment");
+    const BnBwdFin fin{ctr, gamma, (double)count, dgamma, dbeta, coef3};
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C, fin);
+    GN_LAUNCH_CHECK("bn_bwd_reduce_fused");
+    return 0;
+}
+
+int goalnet_bnpool_bwd_fused(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, double* dbias_partials,
+                             int nparts, float* dbias, int* ctr, int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && idx && coef3 && dy && dbias_partials && dbias && ctr, GOALNET_E_NULL, "bnpool_bwd_fused: null pointer");
+    GN_PARTS_OK("bnpool_bwd_fused");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd_fused: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_fused: alignment");
+    hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
+                       dbias_partials, N, Hc, Wc, C, DbiasFin{ctr, dbias});
+    GN_LAUNCH_CHECK("bnpool_bwd_fused");
     return 0;
 }
 

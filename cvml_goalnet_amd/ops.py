@@ -187,6 +187,44 @@ def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C)
                                          _f16(dypad), _s()), "bnpool_bwd_bf16p")
 
 
+SMALL_BN_ELEMS = 1 << 22       # conv outputs up to this many elements take the one-launch pool / BatchNorm kernels
+
+
+def pool_bn_fwd_fused(y, p, idx, partials, gamma, beta, rmean, rvar, momentum, eps, count, st, N, Hc, Wc, C):
+    """pool_bnstats_fwd + bn_finalize in one launch (small fp32 shapes); st = (4, C): mean, invstd, scale, shift"""
+    _chk(y, p, idx, partials, gamma, beta, rmean, rvar, st)
+    _req(y.dtype == F32 and p.dtype == F32 and y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C,
+         "pool_bn_fwd_fused: fp32 y (N,Hc,Wc,C) and p (N,Hc-2,Wc-2,C)")
+    _req(idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel()), "pool_bn_fwd_fused: idx must be uint8, one per pooled element")
+    _req(st.numel() == 4 * C and st.is_contiguous(), "pool_bn_fwd_fused: st must be (4, C)")
+    ctr = _tile_counters(("pool_bn_fwd", N, Hc, Wc, C), y.device)
+    check(lib().goalnet_pool_bn_fwd_fused(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(),
+                                          beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps, count, st[0].data_ptr(), st[1].data_ptr(),
+                                          st[2].data_ptr(), st[3].data_ptr(), ctr.data_ptr(), N, Hc, Wc, C, _s()), "pool_bn_fwd_fused")
+
+
+def bn_bwd_reduce_fused(dz, p, mean, invstd, partials, npix, C, gamma, count, dgamma, dbeta, coef3):
+    """bn_bwd_reduce + bn_bwd_finalize in one launch (small fp32 shapes)"""
+    _chk(dz, p, mean, invstd, partials, gamma, dgamma, dbeta, coef3)
+    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == npix * C, "bn_bwd_reduce_fused: fp32 dz / p of npix * C elements")
+    _req(coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C, "bn_bwd_reduce_fused: coef3 (3 C), dgamma (C), dbeta (C)")
+    ctr = _tile_counters(("bn_bwd_reduce", npix, C), dz.device)
+    check(lib().goalnet_bn_bwd_reduce_fused(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
+                                            _rows(partials, 2 * C), npix, C, gamma.data_ptr(), count, dgamma.data_ptr(), dbeta.data_ptr(),
+                                            coef3.data_ptr(), ctr.data_ptr(), _s()), "bn_bwd_reduce_fused")
+
+
+def bnpool_bwd_fused(dz, p, idx, coef3, dy, dbias_partials, dbias, N, Hc, Wc, C):
+    """bnpool_bwd + the conv bias gradient's partials_sum in one launch (small fp32 shapes)"""
+    _chk(dz, p, idx, coef3, dy, dbias_partials, dbias)
+    npool = N * (Hc - 2) * (Wc - 2) * C
+    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C and dbias.numel() == C,
+         "bnpool_bwd_fused: fp32 dz / p / idx of the pooled shape, dy of the conv shape, dbias (C)")
+    ctr = _tile_counters(("bnpool_bwd", N, Hc, Wc, C), dz.device)
+    check(lib().goalnet_bnpool_bwd_fused(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), dbias_partials.data_ptr(),
+                                         _rows(dbias_partials, C), dbias.data_ptr(), ctr.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd_fused")
+
+
 def partials_sum(partials, nparts, stride, C, out):
     _chk(partials, out)
     _req(partials.dtype == torch.float64 and out.numel() == C, "partials_sum: argument check failed: partials.dtype == torch.float64 and out.numel() == C")
@@ -200,6 +238,22 @@ def partials_sum_f64(partials, C, out):
     check(lib().goalnet_partials_sum_f64(partials.data_ptr(), _rows(partials, C), C, C, out.data_ptr(), _s()), "partials_sum_f64")
 
 
+N_TILE_CTR = 1024
+_TILE_CTR = {}
+_WGRAD_CODES = {}
+
+
+def _tile_counters(key, device):
+    """zeroed int32 ticket counters lent to the fused split-K reduction of one call site (include/goalnet_hip.h: zero on entry,
+    zero again on exit). One tensor per (call site, shape): calls that may overlap on two streams — a weight gradient on the
+    side stream under a data gradient on the main one — never share counters."""
+    k = (key, device.index)
+    t = _TILE_CTR.get(k)
+    if t is None:
+        t = _TILE_CTR[k] = torch.zeros(N_TILE_CTR, dtype=torch.int32, device=device)
+    return t
+
+
 def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     _chk(x, scale, shift, w, bias, y)
     _req(x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin, "conv3x3_fwd: argument check failed: x.numel() == N * H * W * Cin and y.numel() == N * H * W * Cout and w.numel() == Cout * 9 * Cin")
@@ -207,8 +261,9 @@ def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     _req(bias is None or bias.numel() == Cout, "conv3x3_fwd: argument check failed: bias is None or bias.numel() == Cout")
     nbytes = lib().goalnet_conv3x3_fwd_ws_bytes(N, H, W, Cin, Cout)       # > 0 only for small N (split-K slabs)
     ws = torch.empty(nbytes // 4, dtype=F32, device=x.device) if nbytes else None
+    ctr = _tile_counters(("conv3x3_fwd", N, H, W, Cin, Cout, scale is None), x.device) if nbytes else None
     check(lib().goalnet_conv3x3_fwd(x.data_ptr(), _p(scale), _p(shift), w.data_ptr(), _p(bias), int(relu), y.data_ptr(),
-                                    N, H, W, Cin, Cout, _p(ws), nbytes, _s()), "conv3x3_fwd")
+                                    N, H, W, Cin, Cout, _p(ws), nbytes, _p(ctr), N_TILE_CTR if nbytes else 0, _s()), "conv3x3_fwd")
     return y
 
 
@@ -217,8 +272,17 @@ def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
     _req(x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin, "conv3x3_wgrad: argument check failed: x.numel() == N * H * W * Cin and dy.numel() == N * H * W * Cout and dw.numel() == Cout * 9 * Cin")
     nbytes = lib().goalnet_conv3x3_wgrad_ws_bytes(N, H, W, Cin, Cout)
     ws = torch.empty(nbytes // 4, dtype=F32, device=x.device)
+    # the border-code table depends on (N, H, W) only: built once per shape and device, not once per call
+    ck = (N, H, W, x.device.index)
+    codes = _WGRAD_CODES.get(ck)
+    if codes is None:
+        codes = torch.empty(lib().goalnet_conv3x3_wgrad_codes_bytes(N, H, W) // 4, dtype=torch.int32, device=x.device)
+        check(lib().goalnet_conv3x3_wgrad_codes(codes.data_ptr(), N, H, W, _s()), "conv3x3_wgrad_codes")
+        if len(_WGRAD_CODES) < 64 and N * H * W <= (1 << 22):
+            _WGRAD_CODES[ck] = codes
+    ctr = _tile_counters(("conv3x3_wgrad", N, H, W, Cin, Cout), x.device)
     check(lib().goalnet_conv3x3_wgrad(x.data_ptr(), _p(scale), _p(shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-                                      N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
+                                      codes.data_ptr(), ctr.data_ptr(), N_TILE_CTR, N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
     return dw
 
 

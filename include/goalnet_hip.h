@@ -111,6 +111,19 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
                                int f16, void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
+/* Small shapes (the reference's 10-frame sub-batches, main.py:177-196): the pool / BatchNorm passes with their finalise step
+ * folded in — the last block to arrive sums the partial rows in the order of goalnet_bn_finalize / goalnet_bn_bwd_finalize /
+ * goalnet_partials_sum and writes what that separate launch would (same bits), so each pass is ONE launch. fp32 tensors.
+ * ctr: one int32 in device memory, zero on entry, zero again on exit (lend it to later calls on the same stream only). */
+int goalnet_pool_bn_fwd_fused(const float* y, float* p, uint8_t* idx, double* partials, int nparts, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int64_t count,
+                              float* mean, float* invstd, float* scale, float* shift, int* ctr,
+                              int N, int Hc, int Wc, int C, void* stream);
+int goalnet_bn_bwd_reduce_fused(const float* dz, const float* p, const float* mean, const float* invstd, double* partials, int nparts,
+                                int64_t npix, int C, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* coef3,
+                                int* ctr, void* stream);
+int goalnet_bnpool_bwd_fused(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, double* dbias_partials,
+                             int nparts, float* dbias, int* ctr, int N, int Hc, int Wc, int C, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
  * (ddp.SyncStats; SURVEY.md §8(e) "SyncBN": all-reduce of per-channel sum(x), sum(x^2)) */
 int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream);
@@ -123,13 +136,23 @@ int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride,
  * workspace of goalnet_conv3x3_fwd_ws_bytes (0 = not needed) K is split into slabs that are summed in a fixed order.
  * ws may be NULL (no split; same result up to fp32 summation order). */
 size_t goalnet_conv3x3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
+/* tile_ctr (nullable) / n_ctr: int32 ticket counters in device memory, ZERO on entry, one per 128 x 128 output tile; when
+ * given (and K is split) the last block of each tile sums the tile's slabs in split order and applies the epilogue, so the
+ * reduction needs no second launch (same bits as the two-launch form). The library leaves the counters zero again; a
+ * caller may lend the same counters to later calls on the same stream, not to calls that may run concurrently. */
 int goalnet_conv3x3_fwd(const float* x, const float* scale, const float* shift, const float* w_ohwi,
                         const float* bias, int relu, float* y, int N, int H, int W, int Cin, int Cout,
-                        void* ws, size_t ws_bytes, void* stream);
-/* dw[Cout][3][3][Cin] = sum_m dy[m][co] * bnapply(x)[m + tap][ci]; split over m, deterministic. */
+                        void* ws, size_t ws_bytes, int* tile_ctr, int n_ctr, void* stream);
+/* dw[Cout][3][3][Cin] = sum_m dy[m][co] * bnapply(x)[m + tap][ci]; split over m, deterministic.
+ * codes (nullable): the per-pixel border-code table of goalnet_conv3x3_wgrad_codes for the same N, H, W (it depends on
+ * nothing else, so a caller that keeps it saves a launch per call; NULL: built inside ws on every call).
+ * tile_ctr / n_ctr: as for goalnet_conv3x3_fwd (used where no border correction is pending: few frames, or no affine). */
 size_t goalnet_conv3x3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
+size_t goalnet_conv3x3_wgrad_codes_bytes(int N, int H, int W);
+int goalnet_conv3x3_wgrad_codes(uint32_t* codes, int N, int H, int W, void* stream);
 int goalnet_conv3x3_wgrad(const float* x, const float* scale, const float* shift, const float* dy, float* dw,
-                          void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, void* stream);
+                          void* ws, size_t ws_bytes, const uint32_t* codes, int* tile_ctr, int n_ctr,
+                          int N, int H, int W, int Cin, int Cout, void* stream);
 
 /* ---- precision = "bf16" / "fp16" modes: the same contractions on the 16-bit matrix cores (v_mfma_f32_32x32x16_bf16 /
  * v_mfma_f32_32x32x16_f16, fp32 accumulate). Operands are 16-bit copies produced by the cast passes below; everything

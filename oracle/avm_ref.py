@@ -90,14 +90,26 @@ def natural_taps(y: torch.Tensor):
     return taps, gap, pooled
 
 
-def _vis_block(x, p, b, i, stride, pad, inter, taps=None):
-    """conv -> ReLU -> MaxPool(3,1) -> train-mode BatchNorm  (utils.py:174-187)."""
+def _vis_block(x, p, b, i, stride, pad, inter, taps=None, gate=None):
+    """conv -> ReLU -> MaxPool(3,1) -> train-mode BatchNorm  (utils.py:174-187).
+    taps / gate (tests only): the max-pool's argmax positions and the ReLU's gate AT those positions are given. ReLU is as
+    discontinuous as the max-pool's routing: a window maximum within rounding error of zero is passed by one correct fp32
+    convolution (y = +1e-9: the gradient flows) and blocked by another (y = -1e-9), and that one element then shows up at
+    O(1) in the bias / weight gradients of the layer. Parity tests compare backward passes under the device's decisions and
+    check separately that every decision that differs from the oracle's own is such a near-zero (tests/test_gpu_bench_shapes.py)."""
     pre = f"visbl.conv{i}"
     x = F.conv2d(x, p[pre + ".weight"], p[pre + ".bias"], stride=stride, padding=pad)
-    x = F.relu(x)
     if inter is not None:
-        inter[f"visbl.relu{i}"] = x
-    x = F.max_pool2d(x, kernel_size=3, stride=1, padding=0) if taps is None else _ForcedMaxPool.apply(x, taps)
+        inter[pre] = x                                        # pre-activation
+    if taps is not None and gate is not None:
+        if inter is not None:
+            inter[f"visbl.relu{i}"] = F.relu(x)
+        x = _ForcedMaxPool.apply(x, taps) * gate.to(x.dtype)
+    else:
+        x = F.relu(x)
+        if inter is not None:
+            inter[f"visbl.relu{i}"] = x
+        x = F.max_pool2d(x, kernel_size=3, stride=1, padding=0) if taps is None else _ForcedMaxPool.apply(x, taps)
     if inter is not None:
         inter[f"visbl.maxpool{i}"] = x
     bn = f"visbl.bnorm{i}"
@@ -111,25 +123,28 @@ def _vis_block(x, p, b, i, stride, pad, inter, taps=None):
 
 def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visual,
             drop_masks: Optional[List[torch.Tensor]] = None, audio_included: bool = True,
-            inter: Optional[dict] = None, pool_taps: Optional[dict] = None, head: str = "regression") -> torch.Tensor:
+            inter: Optional[dict] = None, pool_taps: Optional[dict] = None, head: str = "regression",
+            relu_gates: Optional[dict] = None) -> torch.Tensor:
     """AVM.forward(audio_input, visual_input) -> (N,1) in (1,5).  utils.py:260-272.
 
     `b` (BN running stats) is updated in place, as the reference's train-mode forward does even under
     no_grad. `drop_masks`: [visbl.drop5, fusion.2, fusion.5, fusion.8, fusion.11] multipliers or None.
     `inter`: optional dict that receives named intermediate activations.
     `pool_taps`: optional {1,2,3 -> uint8 (N,C,Hp,Wp)} argmax positions to force in the three max-pools
-    (tests only, see _ForcedMaxPool); None = the reference's own behaviour.
+    (tests only, see _ForcedMaxPool); None = the reference's own behaviour. `relu_gates`: optional {1,2,3 -> bool (N,C,Hp,Wp)}, with
+    pool_taps: whether the ReLU passes at each forced argmax position (tests only, see _vis_block).
     """
     pt = pool_taps or {}
+    rg = relu_gates or {}
     dm = drop_masks if drop_masks is not None else [None] * 5
 
     def drop(x, m):
         return x if m is None else x * m
 
     # VisBl, utils.py:172-195
-    x = _vis_block(visual, p, b, 1, 3, 3, inter, pt.get(1))
-    x = _vis_block(x, p, b, 2, 1, 1, inter, pt.get(2))
-    x = _vis_block(x, p, b, 3, 1, 1, inter, pt.get(3))
+    x = _vis_block(visual, p, b, 1, 3, 3, inter, pt.get(1), rg.get(1))
+    x = _vis_block(x, p, b, 2, 1, 1, inter, pt.get(2), rg.get(2))
+    x = _vis_block(x, p, b, 3, 1, 1, inter, pt.get(3), rg.get(3))
     x = torch.flatten(x, 1)                                   # NCHW flatten: c*H*W + h*W + w
     x = F.relu(F.linear(x, p["visbl.linear5.weight"], p["visbl.linear5.bias"]))
     v = drop(x, dm[0])
@@ -198,10 +213,10 @@ def adam_step(p: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor], state: dic
 
 
 def train_step(p, b, state, audio, visual, labels, drop_masks=None, audio_included=True, inter=None, pool_taps=None,
-               head="regression"):
+               head="regression", relu_gates=None):
     """One sub-batch train step, main.py:187-193. Returns (loss, pred, grads). `p` is updated in place."""
     leaf = {k: v.detach().requires_grad_(True) for k, v in p.items()}
-    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter, pool_taps, head)
+    pred = forward(leaf, b, audio, visual, drop_masks, audio_included, inter, pool_taps, head, relu_gates)
     loss = ce_loss(pred, labels) if head == "classifier" else mse_bcast(pred, labels)
     names = list(leaf.keys())
     grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)

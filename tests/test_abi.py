@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_do_not_need_a_gpu():
     """Shape/NULL checks run before any launch and return negative codes with a message."""
     lib = _lib.load()
-    rc = lib.goalnet_conv3x3_fwd(None, None, None, None, None, 0, None, 1, 8, 8, 64, 64, None, 0, None)
+    rc = lib.goalnet_conv3x3_fwd(None, None, None, None, None, 0, None, 1, 8, 8, 64, 64, None, 0, None, 0, None)
     assert rc == -1 and b"null" in lib.goalnet_last_error()
     # ten 11x11 frames (the reference's sub-batch at 40x40) need split-K slabs, 1024 frames of 72x72 do not
     assert lib.goalnet_conv3x3_fwd_ws_bytes(10, 11, 11, 256, 512) > 0

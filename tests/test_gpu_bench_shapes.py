@@ -13,6 +13,11 @@ step at that resolution, so a 1 024-frame oracle step is out of reach; two const
   the BatchNorm-3 output gradient to their bf16 forms (`bf5 / p16_3 / y16_3 / o16_3`); forward and backward are compared
   with the oracle under the device's max-pool routing.
 
+Both max-pool routing and the ReLU gate at the routed position are discontinuous in the convolution's output; the backward
+comparison runs the oracle under the DEVICE's decisions for both (oracle/avm_ref.py: _ForcedMaxPool, _vis_block) and every
+decision that differs from the oracle's own must be a near-tie / a near-zero (round 3: one window maximum of +-1e-9 among
+42 M activations put a whole 8e-8 into conv3's bias gradient for one data seed).
+
 Tolerances. fp32: predictions / logits 2e-5 abs, loss 2e-5 rel; every gradient tensor as close to an fp64 run of the oracle
 (same routing) as the oracle's own fp32 arithmetic is (x 4) or within 2e-6 sqrt(copies) of its magnitude — a batch of
 1 024 frames sums 64 x more terms than the 16-frame oracle step, so a fixed relative bound against the fp32 oracle would
@@ -59,6 +64,26 @@ def _taps_first(ctx, k):
     return out
 
 
+def _gates_first(ctx, k):
+    """the ReLU gates the device's backward applies at the argmax positions — (p > 0), csrc/pool_bn.hip reads the mask off the
+    pooled value — of the first k frames as (k, C, Hp, Wp) bool CPU tensors"""
+    return {i: (ctx[f"p{i}"][:k].float() > 0).cpu().permute(0, 3, 1, 2).contiguous() for i in (1, 2, 3)}
+
+
+def gate_disagreements(inter, taps, gates):
+    """windows whose ReLU gate at the device's argmax position differs from the oracle's own (y > 0 there), and the largest |y|
+    among them relative to the layer's max |y|: legitimate only within the convolution's rounding error of zero"""
+    count, worst = 0, 0.0
+    for i in (1, 2, 3):
+        y = inter[f"visbl.conv{i}"].detach()
+        at = avm_ref._ForcedMaxPool.apply(y, taps[i])
+        diff = (at > 0) != gates[i]
+        if diff.any():
+            count += int(diff.sum())
+            worst = max(worst, float(at[diff].abs().max()) / float(y.abs().max()))
+    return count, worst
+
+
 def _run_case(precision, h, n_unique, copies, data_seed=synth.BASE_SEED, model_seed=7):
     """one fused train step on `copies` x the same `n_unique` frames, pinned by one oracle step on the n_unique frames.
     Returns the model (after the step) and the device inputs, for callers that go on (tests/test_gpu_ddp_cfg4.py)."""
@@ -88,6 +113,7 @@ def _run_case(precision, h, n_unique, copies, data_seed=synth.BASE_SEED, model_s
         for c in {0, copies // 2, copies - 1}:
             assert torch.equal(raw[c], raw[0]), f"block {i}: copy {c} routed its max-pool differently from copy 0"
     taps = _taps_first(ctx, n_unique)
+    gates = _gates_first(ctx, n_unique) if precision == "fp32" else None
     logit = model.last_logit[:n_unique].cpu()
     del ctx
     gc.collect()
@@ -102,13 +128,16 @@ def _run_case(precision, h, n_unique, copies, data_seed=synth.BASE_SEED, model_s
     # 16-bit modes round the conv outputs, so their argmax differs from ATen's in thousands of windows by construction; the
     # routing check (an unfold + top-2 over every window) is only meaningful — and only run — for the fp32 engine
     nd, worst = routing_disagreements(inter, taps) if fp32 else (-1, float("nan"))
+    ng, gworst = gate_disagreements(inter, taps, gates) if fp32 else (-1, float("nan"))
     del inter
     gc.collect()
     e_logit = (logit - ref_logit).abs()
     print(f"[parity] {precision} {n}x{h}x{h} ({copies} x {n_unique}): logit error vs CPU oracle mean {e_logit.mean():.2e} max {e_logit.max():.2e}; "
-          f"{nd} max-pool windows routed differently (largest top-2 gap {worst:.2e} of max|y|)")
+          f"{nd} max-pool windows routed differently (largest top-2 gap {worst:.2e} of max|y|); {ng} ReLU gates at the argmax "
+          f"differ (largest |y| there {gworst:.2e} of max|y|)")
     if fp32:
         assert worst <= NEAR_TIE, "max-pool argmax differs from ATen's where the window is NOT a near-tie"
+        assert gworst <= NEAR_TIE, "the ReLU gate at a window's argmax differs from the oracle's where y is NOT within rounding of zero"
         if nd == 0:
             assert e_logit.max().item() <= 2e-5
     else:
@@ -119,14 +148,14 @@ def _run_case(precision, h, n_unique, copies, data_seed=synth.BASE_SEED, model_s
         # (tests/test_gpu_avm.py::test_gradients_within_reference_rounding_of_fp64_truth, here at the bench's size)
         p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
         pred64 = avm_ref.forward(p64, avm_ref.init_buffers(torch.float64), aud.double(), vis.double(), [m.double() for m in masks], True,
-                                 None, pool_taps=taps)
+                                 None, pool_taps=taps, relu_gates=gates)
         avm_ref.mse_bcast(pred64, lab.double()).backward()
         g64 = {k: v.grad for k, v in p64.items()}
         pred64 = pred64.detach()
         del p64
         gc.collect()
     state = {}
-    o_loss, o_pred, o_g = avm_ref.train_step(p, b, state, aud, vis, lab, masks, True, pool_taps=taps)
+    o_loss, o_pred, o_g = avm_ref.train_step(p, b, state, aud, vis, lab, masks, True, pool_taps=taps, relu_gates=gates)
     perr = (pred[:n_unique].cpu().view(-1, 1) - o_pred).abs().max().item()
     lerr = abs(loss.item() - o_loss.item()) / max(1.0, abs(o_loss.item()))
     print(f"[parity] {precision} {n}x{h}x{h}: |pred - oracle| {perr:.2e}, loss rel err {lerr:.2e} (same routing)")

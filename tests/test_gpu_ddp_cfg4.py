@@ -83,6 +83,10 @@ def _worker(rank, port, tmp):
             gc.collect()
             torch.cuda.empty_cache()
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    except BaseException:
+        import traceback
+        open(os.path.join(tmp, f"err{rank}.txt"), "w").write(traceback.format_exc())     # the parent prints BOTH ranks' errors
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -90,5 +94,10 @@ def _worker(rank, port, tmp):
 def test_cfg4_per_gpu_shape_128_frames_of_224_two_ranks_standard_ddp_and_sharded_linear5(tmp_path):
     import torch.multiprocessing as mp
     port = 24500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    try:
+        mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    finally:
+        for k in range(WORLD):
+            if (tmp_path / f"err{k}.txt").exists():
+                print(f"---- rank {k} ----\n" + (tmp_path / f"err{k}.txt").read_text())
     assert all((tmp_path / f"ok{k}").exists() for k in range(WORLD))
