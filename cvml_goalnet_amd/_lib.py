@@ -45,9 +45,8 @@ PROTOTYPES = {
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_pool_bn_fwd_fused": (c_int, [P, P, P, P, c_int, P, P, P, P, c_float, c_float, c_int64, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bn_bwd_reduce_fused": (c_int, [P, P, P, P, P, c_int, c_int64, c_int, P, c_int64, P, P, P, P, P]),
-    "goalnet_bnpool_bwd_fused": (c_int, [P, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_pool_bn_fwd_small": (c_int, [P, P, P, P, P, P, P, c_float, c_float, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bn_pool_bwd_small": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -89,6 +88,10 @@ PROTOTYPES = {
     "goalnet_conv1d_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "goalnet_conv1d_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "goalnet_relu_bwd": (c_int, [P, P, P, c_int64, P]),
+    "goalnet_mlp_blocks": (c_int, []),
+    "goalnet_mlp_fwd": (c_int, [P, c_int64, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "goalnet_mlp_bwd_ws_bytes": (c_size_t, [c_int]),
+    "goalnet_mlp_bwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int, c_int, c_int, P, c_size_t, P, P]),
     "goalnet_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, P]),
     "goalnet_head_bwd": (c_int, [P, P, P, c_int64, P, P, c_int64, P, c_int64, P, P, c_int, c_int, P]),
     "goalnet_mse_bcast": (c_int, [P, P, c_int, P, P, P]),

@@ -536,9 +536,13 @@ class AVM(nn.Module):
         pooled activation the fused backward can read back"""
         return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536 and AVM._bwd16_ok(wc)
 
+    def _mlp_fused(self, n):
+        """the one-launch fusion MLP (csrc/mlp.hip): the regression head at the reference's sub-batch sizes"""
+        return n <= 16 and self.head == "regression" and os.environ.get("GOALNET_MLP_FUSED", "1") != "0"
+
     def _small_bn(self, a, b, n, hc, wc, c):
         """the one-launch pool / BatchNorm kernels (csrc/pool_bn.hip, goalnet_*_fused): fp32 tensors, local statistics, few elements"""
-        return (a.dtype == F32 and b.dtype == F32 and self.stat_sync is None and n * hc * wc * c <= ops.SMALL_BN_ELEMS
+        return (a.dtype == F32 and b.dtype == F32 and self.stat_sync is None and n * hc * wc <= ops.SMALL_BN_PIXELS
                 and os.environ.get("GOALNET_SMALL_BN", "1") != "0")
 
     def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
@@ -553,9 +557,8 @@ class AVM(nn.Module):
         count = n * (hc - 2) * (wc - 2)
         if self._small_bn(y, p, n, hc, wc, c):
             # the reference's operating point (10 frames of 40 x 40): pool, statistics AND the finalise step in one launch
-            partials = torch.empty(ops.stat_parts(max(8 * n, min(count * c // 1024, 256))) * 2 * c, dtype=torch.float64, device=dev)
-            ops.pool_bn_fwd_fused(y, p, idx, partials, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
-                                  bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, count, st, n, hc, wc, c)
+            ops.pool_bn_fwd_small(y, p, idx, self._pflat(f"visbl.bnorm{i}.weight"), self._pflat(f"visbl.bnorm{i}.bias"),
+                                  bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, st, n, hc, wc, c)
             bn.num_batches_tracked += 1
             return p, idx, st
         # one partial row per (frame, row band): up to 8 bands per frame keep the grid full for small sub-batches
@@ -676,14 +679,28 @@ class AVM(nn.Module):
         # ---- fusion, utils.py:242-258, 269-270
         hs, ms = [cat], [mcat]
         x = cat
-        for li, (key, width) in enumerate((("0", 512), ("3", 512), ("6", 256), ("9", 128))):
+        fused_mlp = self._mlp_fused(n)
+        if fused_mlp:
+            # the reference's sub-batch size: the five layers, the Sigmoid and 4y+1 in ONE launch (csrc/mlp.hip)
+            keys = ("0", "3", "6", "9", "12")
+            for width in ops.MLP_WIDTHS:
+                hs.append(torch.empty(n, width, dtype=F32, device=dev))
+                ms.append(torch.empty(n, width, dtype=F32, device=dev) if save else None)
+            logit = torch.empty(n, dtype=F32, device=dev)
+            out = torch.empty(n, dtype=F32, device=dev)
+            ops.mlp_fwd(cat, [P(f"fusion.{k}.weight") for k in keys], [P(f"fusion.{k}.bias") for k in keys], masks[1:5],
+                        hs[1:], ms[1:], logit, out)
+            x = hs[4]
+        for li, (key, width) in enumerate(() if fused_mlp else (("0", 512), ("3", 512), ("6", 256), ("9", 128))):
             hnext = torch.empty(n, width, dtype=F32, device=dev)
             m = torch.empty(n, width, dtype=F32, device=dev) if save else None
             ops.linear_fwd(x, P(f"fusion.{key}.weight"), P(f"fusion.{key}.bias"), hnext, relu=True,
                            dropmask=masks[1 + li], mult_out=m)
             hs.append(hnext); ms.append(m)
             x = hnext
-        if self.head == "classifier":
+        if fused_mlp:
+            pass
+        elif self.head == "classifier":
             logit = torch.empty(n, self.num_classes, dtype=F32, device=dev)
             out = torch.empty(n, self.num_classes, dtype=F32, device=dev)          # class scores 4 softmax(z) + 1
             ops.cls_head_fwd(x, P("fusion.12.weight"), P("fusion.12.bias"), logit, out)
@@ -704,17 +721,14 @@ class AVM(nn.Module):
         G = self._gflat
         p, idx, st = ctx[f"p{i}"], ctx[f"idx{i}"], ctx[f"st{i}"]
         npix = n * (hc - 2) * (wc - 2)
-        coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         small = self._small_bn(dbn, p, n, hc, wc, c) and not (self._half and i > 1)
         if small:
-            # the reference's operating point: reduce + finalise in one launch, then the fused backward + bias gradient in one
-            partials = torch.empty(ops.stat_parts(max(npix // 64, min(npix * c // 1024, 128))) * 2 * c, dtype=torch.float64, device=dev)
-            ops.bn_bwd_reduce_fused(dbn, p, st[0], st[1], partials, npix, c, self._pflat(f"visbl.bnorm{i}.weight"), npix,
-                                    G(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.bias"), coef3)
-            dparts = torch.empty(ops.stat_parts(max(8 * n, min(n * hc * wc * c // 1024, 256))) * c, dtype=torch.float64, device=dev)
+            # the reference's operating point: BatchNorm backward, max-pool / ReLU backward and the bias gradient in ONE launch
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
-            ops.bnpool_bwd_fused(dbn, p, idx, coef3, dy, dparts, G(f"visbl.conv{i}.bias"), n, hc, wc, c)
+            ops.bn_pool_bwd_small(dbn, p, idx, st[0], st[1], self._pflat(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.weight"),
+                                  G(f"visbl.bnorm{i}.bias"), dy, G(f"visbl.conv{i}.bias"), n, hc, wc, c)
             return dy
+        coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
         ops.bn_bwd_reduce(dbn, p, st[0], st[1], partials, npix, c)
         ops.bn_bwd_finalize(partials, self._pflat(f"visbl.bnorm{i}.weight"), st[0], st[1], npix, c,
@@ -767,13 +781,19 @@ class AVM(nn.Module):
                 on_bucket(k)
 
         # head + fusion MLP (reverse of utils.py:242-258)
-        dz = torch.empty(n, 128, dtype=F32, device=dev)
-        if self.head == "classifier":
+        fused_mlp = self._mlp_fused(n) and ms[0] is not None
+        dz = torch.empty(n, hs[0].shape[1] if fused_mlp else 128, dtype=F32, device=dev)
+        if fused_mlp:
+            # one launch: the five layers' dW / db, the dX chain down to the gradient behind `cat`, and linear5's bias gradient
+            keys = ("0", "3", "6", "9", "12")
+            ops.mlp_bwd(dout, ctx["out"], hs, ms, [P(f"fusion.{k}.weight") for k in keys], [G(f"fusion.{k}.weight") for k in keys],
+                        [G(f"fusion.{k}.bias") for k in keys], dz, G("visbl.linear5.bias"), dz.shape[1] - 512)
+        elif self.head == "classifier":
             ops.cls_head_bwd(dout.view(n, self.num_classes), ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz,
                              G("fusion.12.weight"), G("fusion.12.bias"))
         else:
             ops.head_bwd(dout, ctx["out"], hs[4], P("fusion.12.weight"), ms[4], dz, G("fusion.12.weight"), G("fusion.12.bias"))
-        for key, li in (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
+        for key, li in () if fused_mlp else (("9", 3), ("6", 2), ("3", 1), ("0", 0)):
             x_in, m_in = hs[li], ms[li]
             fork.run(lambda dz=dz, x_in=x_in, key=key: ops.linear_bwd_dw(dz, x_in, G(f"fusion.{key}.weight"), db=G(f"fusion.{key}.bias")), dz)
             dprev = torch.empty(n, x_in.shape[1], dtype=F32, device=dev)
@@ -797,7 +817,8 @@ class AVM(nn.Module):
                 ops.relu_bwd(da1, ctx["a1"], da1)
                 ops.conv1d_bwd(ctx["audio"], da1, P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
             fork.run(audbl_bwd, dz)
-        fork.run(lambda: ops.colsum(dz5, G("visbl.linear5.bias")), dz)
+        if not fused_mlp:
+            fork.run(lambda: ops.colsum(dz5, G("visbl.linear5.bias")), dz)
         bucket_done(0)
 
         # linear5 (utils.py:191): dW straight into the arena, dX = grad wrt bnorm3's output

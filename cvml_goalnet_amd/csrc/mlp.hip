@@ -1,0 +1,378 @@
+// The fusion MLP + head (/root/reference/utils.py:242-258, 269-270) and its backward (autograd of main.py:192) at the
+// reference's operating point — sub-batches of <= 16 frames (main.py:44, 177-184) — as ONE launch per direction.
+//
+// With 10 rows the five layers (640 -> 512 -> 512 -> 256 -> 128 -> 1, 3 MB of weights) are a chain of latency-bound weight
+// streams: as separate launches (csrc/skinny.hip: 6 forward, 12 backward) each costs its own launch gap and ramp although it
+// runs 4 - 8 us. Here 64 blocks stay resident and walk the layers together; between layers they meet at a grid barrier
+// (an arrival counter in device memory, release / acquire fences at agent scope: the layer's outputs are written by blocks on
+// other XCDs, whose L2 is not coherent with this one's). The barrier is bounded: a block that does not see the others
+// arrive within ~1 s sets an error word and every block leaves — no wave can spin forever. 64 blocks of 256 threads are
+// always co-resident on 256 CUs, also beside other kernels of the step (side-stream work, graph branches).
+//
+// All sums run in a fixed order (deterministic); fp32 throughout, as the reference.
+#include "common.h"
+
+using namespace goalnet;
+
+namespace {
+
+constexpr int MLP_BLOCKS = 64;
+constexpr int KMAX = 640;                 // widest layer input (fusion.0 with audio: 128 + 512)
+constexpr int SPIN_LIMIT = 1 << 22;       // x s_sleep(2) + an atomic load: about a second
+
+struct MlpFwdP {
+    const float* x0; int64_t ldx0; int K0;          // cat (n, K0), row stride ldx0
+    const float* w[5]; const float* b[5];           // fusion.0, .3, .6, .9, .12
+    const float* mask[4]; int64_t ldmask[4];        // dropout multipliers of fusion.2, .5, .8, .11 (nullable)
+    float* h[4];                                    // layer outputs (n, J[l]), contiguous
+    float* mult[4];                                 // (pre-activation > 0) * mask, saved for backward (nullable)
+    float* logit; float* out;                       // (n)
+    int n; int J[4];
+    int* sync;                                      // [0] arrivals, [1] departures, [2] error flag; zero on entry / exit
+};
+
+struct MlpBwdP {
+    const float* dout; const float* out;            // (n)
+    const float* x[5]; int64_t ldx0;                // layer inputs: cat (n, K0; row stride ldx0), h1 .. h4 (contiguous)
+    const float* m[5]; int64_t ldm0;                // saved multipliers of those inputs: mcat (row stride ldm0), m1 .. m4 (nullable)
+    const float* w[5];
+    float* dw[5]; float* db[5];
+    float* dz[4];                                   // scratch: gradients wrt the pre-activations of layers 0..3's OUTPUTS' inputs, see kernel
+    float* dcat; int64_t lddcat;                    // (n, K0): gradient wrt the pre-activations behind `cat` (linear5 | audbl.linear3)
+    float* db5; int voff;                           // visbl.linear5.bias gradient = column sums of dcat[:, voff:] (nullable)
+    int n; int K0; int J[4];
+    int* sync;
+};
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// phase = 1, 2, ...: returns false when the other blocks did not arrive in time (the caller leaves at once)
+__device__ __forceinline__ bool grid_barrier(int* sync, int phase, int nblocks) {
+    __shared__ int s_ok;
+    __threadfence();                       // release: this block's global writes of the phase
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sync[0], 1);
+        const int target = phase * nblocks;
+        int spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < SPIN_LIMIT) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+        }
+        s_ok = spins < SPIN_LIMIT;
+        if (!s_ok) sync[2] = 1;
+    }
+    __syncthreads();
+    __threadfence();                       // acquire: the other blocks' writes
+    return s_ok != 0;
+}
+
+// after the last phase: the last block to leave restores the counters for the next launch
+__device__ __forceinline__ void grid_leave(int* sync, int nblocks) {
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(&sync[1], 1);
+        if (old == nblocks - 1) { sync[0] = 0; sync[1] = 0; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+template <int MR>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
+    __shared__ __attribute__((aligned(16))) float xs[MR * KMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int gw = blockIdx.x * 4 + wv, NW = gridDim.x * 4;
+    for (int l = 0; l < 4; ++l) {
+        const int K = l == 0 ? P.K0 : P.J[l - 1];
+        const float* x = l == 0 ? P.x0 : P.h[l - 1];
+        const int64_t ldx = l == 0 ? P.ldx0 : (int64_t)K;
+        const int J = P.J[l];
+        const float* W = P.w[l];
+        const int kq = K >> 2;
+        __syncthreads();                                       // xs of the previous layer has been read by every wave
+        for (int i = tid; i < MR * kq; i += 256) {
+            const int m = i / kq, q = i - m * kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < P.n) v = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + q * 4);
+            *reinterpret_cast<float4*>(&xs[m * KMAX + q * 4]) = v;
+        }
+        __syncthreads();
+        for (int j = gw; j < J; j += NW) {
+            float acc[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 w4 = *reinterpret_cast<const float4*>(W + (int64_t)j * K + k);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m] += dot4(w4, *reinterpret_cast<const float4*>(&xs[m * KMAX + k]));
+            }
+            float mine = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float v = wave_sum_dpp(acc[m]);
+                if (lane == m) mine = v;
+            }
+            if (lane < P.n) {
+                float v = mine + P.b[l][j];
+                float g = v > 0.f ? 1.f : 0.f;
+                v = v > 0.f ? v : 0.f;
+                if (P.mask[l]) { const float mk = P.mask[l][(int64_t)lane * P.ldmask[l] + j]; v *= mk; g *= mk; }
+                P.h[l][(int64_t)lane * J + j] = v;
+                if (P.mult[l]) P.mult[l][(int64_t)lane * J + j] = g;
+            }
+        }
+        if (l < 3 || blockIdx.x == 0) {
+            if (!grid_barrier(P.sync, l + 1, gridDim.x)) return;
+        } else {
+            // the head runs in block 0 only: the other blocks announce their layer-9 outputs and leave
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) atomicAdd(&P.sync[0], 1);
+        }
+    }
+    if (blockIdx.x == 0) {
+        // head (utils.py:255-256, 270): z = h4 . w12 + b12; out = 4 sigmoid(z) + 1. One wave per row.
+        const int K = P.J[3];
+        for (int m = wv; m < P.n; m += 4) {
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) acc = fmaf(P.h[3][(int64_t)m * K + k], P.w[4][k], acc);
+            acc = wave_sum_dpp(acc);
+            if (lane == 0) {
+                const float z = acc + P.b[4][0];
+                P.logit[m] = z;
+                P.out[m] = 4.f / (1.f + expf(-z)) + 1.f;
+            }
+        }
+    }
+    grid_leave(P.sync, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward. Layer l (weights w[l]: J_l x K_l) has input x[l] (n, K_l) and output gradient g_l (n, J_l) wrt its pre-activation:
+//   dW_l[j][k] = sum_m g_l[m][j] x[l][m][k],   db_l[j] = sum_m g_l[m][j],   g_{l-1}[m][k] = (sum_j g_l[m][j] w[l][j][k]) m[l][m][k]
+// g_4 (the head's input gradient) is n x 128 values computed from dout / out by every block for itself; g_3 .. g_0 travel
+// through dz[3] .. dz[0] in global memory with a grid barrier in between; the gradient behind `cat` (linear5's and
+// audbl.linear3's pre-activations) is dcat.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dlogit_of(float dout, float out) {
+    const float s = (out - 1.f) * 0.25f;                     // d/dz (4 sigmoid(z) + 1) = 4 s (1 - s)
+    return dout * 4.f * s * (1.f - s);
+}
+
+constexpr int KL = 4;                 // dX: k-float4s per block item
+constexpr int JG = 256 / KL;          // dX: j-groups per block
+
+template <int MR>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdP P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // max(512 * MR floats, 256 * MR float4)
+    __shared__ float s_dl[MR];
+    const int tid = threadIdx.x;
+    const int NB = gridDim.x;
+    if (tid < MR) s_dl[tid] = tid < P.n ? dlogit_of(P.dout[tid], P.out[tid]) : 0.f;
+    __syncthreads();
+    if (blockIdx.x == NB - 1) {
+        // head's own parameters: dw12[k] = sum_m dlogit[m] h4[m][k], db12 = sum_m dlogit[m] (rows in index order)
+        const int K = P.J[3];
+        for (int k = tid; k <= K; k += 256) {
+            float t = 0.f;
+            for (int m = 0; m < P.n; ++m) t += k < K ? s_dl[m] * P.x[4][(int64_t)m * K + k] : s_dl[m];
+            if (k < K) P.dw[4][k] = t; else P.db[4][0] = t;
+        }
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int J = P.J[l];
+        const int K = l == 0 ? P.K0 : P.J[l - 1];
+        const float* x = P.x[l];
+        const int64_t ldx = l == 0 ? P.ldx0 : (int64_t)K;
+        const float* W = P.w[l];
+        // ---- stage g_l as gs[j][m] (one b128 read gives four rows)
+        __syncthreads();
+        if (l == 3) {
+            for (int i = tid; i < J * MR; i += 256) {
+                const int j = i / MR, m = i - j * MR;
+                float v = 0.f;
+                if (m < P.n) { v = s_dl[m] * P.w[4][j]; if (P.m[4]) v *= P.m[4][(int64_t)m * J + j]; }
+                sm[i] = v;
+            }
+        } else {
+            for (int i = tid; i < J * MR; i += 256) {
+                const int j = i / MR, m = i - j * MR;
+                sm[i] = m < P.n ? P.dz[l][(int64_t)m * J + j] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- dW_l, db_l: items = (k-float4, group of 8 output rows); the thread keeps its MR x-values in registers
+        const int kq = K >> 2, jch = (J + 7) >> 3;
+        for (int it = blockIdx.x * 256 + tid; it < kq * jch; it += NB * 256) {
+            const int q = it % kq, jc = it / kq;
+            float4 x4[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) x4[m] = m < P.n ? *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int j1 = jc * 8 + 8 < J ? jc * 8 + 8 : J;
+            for (int j = jc * 8; j < j1; ++j) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int mq = 0; mq < MR / 4; ++mq) {
+                    const float4 d = *reinterpret_cast<const float4*>(&sm[j * MR + mq * 4]);
+                    s.x += d.x * x4[mq * 4].x + d.y * x4[mq * 4 + 1].x + d.z * x4[mq * 4 + 2].x + d.w * x4[mq * 4 + 3].x;
+                    s.y += d.x * x4[mq * 4].y + d.y * x4[mq * 4 + 1].y + d.z * x4[mq * 4 + 2].y + d.w * x4[mq * 4 + 3].y;
+                    s.z += d.x * x4[mq * 4].z + d.y * x4[mq * 4 + 1].z + d.z * x4[mq * 4 + 2].z + d.w * x4[mq * 4 + 3].z;
+                    s.w += d.x * x4[mq * 4].w + d.y * x4[mq * 4 + 1].w + d.z * x4[mq * 4 + 2].w + d.w * x4[mq * 4 + 3].w;
+                }
+                *reinterpret_cast<float4*>(P.dw[l] + (int64_t)j * K + q * 4) = s;
+            }
+        }
+        for (int j = blockIdx.x * 256 + tid; j < J; j += NB * 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) t += sm[j * MR + m];
+            P.db[l][j] = t;
+        }
+        // ---- g_{l-1} (or dcat): block items of KL k-float4s; 64 j-groups per item, reduced through LDS in a fixed order
+        float* dst = l == 0 ? P.dcat : P.dz[l - 1];
+        const int64_t lddst = l == 0 ? P.lddcat : (int64_t)K;
+        const float* mul = P.m[l];
+        const int64_t ldmul = l == 0 ? P.ldm0 : (int64_t)K;
+        const int nitems = (kq + KL - 1) / KL;
+        const int kl = tid % KL, jg = tid / KL;
+        float4* red = reinterpret_cast<float4*>(sm);                  // red[jg][m][kl], aliases gs
+        for (int it = blockIdx.x; it < nitems; it += NB) {
+            const int k = (it * KL + kl) * 4;
+            const bool kok = k < K;
+            float4 acc[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int j = jg; j < J; j += JG) {
+                const float4 w4 = kok ? *reinterpret_cast<const float4*>(W + (int64_t)j * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int mq = 0; mq < MR / 4; ++mq) {
+                    const float4 d = *reinterpret_cast<const float4*>(&sm[j * MR + mq * 4]);
+                    acc[mq * 4 + 0].x += d.x * w4.x; acc[mq * 4 + 0].y += d.x * w4.y; acc[mq * 4 + 0].z += d.x * w4.z; acc[mq * 4 + 0].w += d.x * w4.w;
+                    acc[mq * 4 + 1].x += d.y * w4.x; acc[mq * 4 + 1].y += d.y * w4.y; acc[mq * 4 + 1].z += d.y * w4.z; acc[mq * 4 + 1].w += d.y * w4.w;
+                    acc[mq * 4 + 2].x += d.z * w4.x; acc[mq * 4 + 2].y += d.z * w4.y; acc[mq * 4 + 2].z += d.z * w4.z; acc[mq * 4 + 2].w += d.z * w4.w;
+                    acc[mq * 4 + 3].x += d.w * w4.x; acc[mq * 4 + 3].y += d.w * w4.y; acc[mq * 4 + 3].z += d.w * w4.z; acc[mq * 4 + 3].w += d.w * w4.w;
+                }
+            }
+            __syncthreads();                                          // every thread has read gs: the buffer becomes red[]
+#pragma unroll
+            for (int m = 0; m < MR; ++m) red[(jg * MR + m) * KL + kl] = acc[m];
+            __syncthreads();
+            const int m = tid / KL;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < MR) {
+#pragma unroll 16
+                for (int g = 0; g < JG; ++g) {
+                    const float4 v = red[(g * MR + m) * KL + kl];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                if (m < P.n && kok) {
+                    if (mul) {
+                        const float4 mv = *reinterpret_cast<const float4*>(mul + (int64_t)m * ldmul + k);
+                        s.x *= mv.x; s.y *= mv.y; s.z *= mv.z; s.w *= mv.w;
+                    }
+                    *reinterpret_cast<float4*>(dst + (int64_t)m * lddst + k) = s;
+                } else {
+                    s = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (l == 0 && P.db5) {
+                // visbl.linear5.bias gradient: column sums of dcat[:, voff:], rows added in index order
+                __syncthreads();
+                if (m < MR) red[m * KL + kl] = s;
+                __syncthreads();
+                if (tid < KL && k >= P.voff && kok) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int mm = 0; mm < MR; ++mm) { const float4 v = red[mm * KL + kl]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                    *reinterpret_cast<float4*>(P.db5 + (k - P.voff)) = t;
+                }
+            }
+            // the next item re-stages nothing (gs is gone): one item per block and layer is the design point (nitems <= NB)
+            break;
+        }
+        if (l > 0) {
+            if (!grid_barrier(P.sync, 4 - l, NB)) return;
+        }
+    }
+    grid_leave(P.sync, NB);
+}
+
+int rows_class(int M) { return M <= 4 ? 4 : M <= 8 ? 8 : M <= 12 ? 12 : 16; }
+
+}  // namespace
+
+extern "C" {
+
+int goalnet_mlp_blocks(void) { return MLP_BLOCKS; }
+
+int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const* w, const float* const* b,
+                    const float* const* mask, const int64_t* ldmask, float* const* h, float* const* mult,
+                    float* logit, float* out, int n, int* sync, void* stream) {
+    GN_REQUIRE(cat && w && b && mask && ldmask && h && mult && logit && out && sync, GOALNET_E_NULL, "mlp_fwd: null pointer");
+    GN_REQUIRE(n >= 1 && n <= 16, GOALNET_E_SHAPE, "mlp_fwd: 1..16 rows (the reference's sub-batches)");
+    GN_REQUIRE(K0 > 0 && K0 <= KMAX && K0 % 4 == 0 && ldcat % 4 == 0 && aligned16(cat), GOALNET_E_SHAPE, "mlp_fwd: K0 must be a multiple of 4, <= 640");
+    MlpFwdP P;
+    P.x0 = cat; P.ldx0 = ldcat; P.K0 = K0;
+    const int J[4] = {512, 512, 256, 128};
+    for (int l = 0; l < 5; ++l) {
+        GN_REQUIRE(w[l] && b[l] && aligned16(w[l]), GOALNET_E_NULL, "mlp_fwd: null / misaligned weight %d", l);
+        P.w[l] = w[l]; P.b[l] = b[l];
+    }
+    for (int l = 0; l < 4; ++l) {
+        GN_REQUIRE(h[l] && aligned16(h[l]), GOALNET_E_NULL, "mlp_fwd: null / misaligned output %d", l);
+        P.mask[l] = mask[l]; P.ldmask[l] = ldmask[l]; P.h[l] = h[l]; P.mult[l] = mult[l]; P.J[l] = J[l];
+    }
+    P.logit = logit; P.out = out; P.n = n; P.sync = sync;
+    hipStream_t st = (hipStream_t)stream;
+    switch (rows_class(n)) {
+        case 4: hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
+        case 8: hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
+        case 12: hipLaunchKernelGGL(mlp_fwd_kernel<12>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
+        default: hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
+    }
+    GN_LAUNCH_CHECK("mlp_fwd");
+    return 0;
+}
+
+size_t goalnet_mlp_bwd_ws_bytes(int n) { return (size_t)n * (512 + 512 + 256 + 128) * sizeof(float); }
+
+int goalnet_mlp_bwd(const float* dout, const float* out, const float* const* x, int64_t ldcat, const float* const* m, int64_t ldmcat,
+                    const float* const* w, float* const* dw, float* const* db, float* dcat, int64_t lddcat, float* db5, int voff,
+                    int n, int K0, void* ws, size_t ws_bytes, int* sync, void* stream) {
+    GN_REQUIRE(dout && out && x && m && w && dw && db && dcat && ws && sync, GOALNET_E_NULL, "mlp_bwd: null pointer");
+    GN_REQUIRE(n >= 1 && n <= 16, GOALNET_E_SHAPE, "mlp_bwd: 1..16 rows (the reference's sub-batches)");
+    GN_REQUIRE(K0 > 0 && K0 <= KMAX && K0 % 4 == 0 && ldcat % 4 == 0 && lddcat % 4 == 0 && ldmcat % 4 == 0 && voff % 4 == 0 && voff >= 0 && voff < K0,
+               GOALNET_E_SHAPE, "mlp_bwd: K0 / leading dims / voff must be multiples of 4");
+    GN_REQUIRE(ws_bytes >= goalnet_mlp_bwd_ws_bytes(n) && aligned16(ws) && aligned16(dcat) && aligned16(db5), GOALNET_E_WORKSPACE, "mlp_bwd: workspace too small or misaligned");
+    MlpBwdP P;
+    P.dout = dout; P.out = out; P.ldx0 = ldcat; P.ldm0 = ldmcat;
+    const int J[4] = {512, 512, 256, 128};
+    for (int l = 0; l < 5; ++l) {
+        GN_REQUIRE(x[l] && w[l] && dw[l] && db[l] && aligned16(x[l]) && aligned16(w[l]) && aligned16(dw[l]) && aligned16(m[l]), GOALNET_E_NULL,
+                   "mlp_bwd: null / misaligned pointer of layer %d", l);
+        P.x[l] = x[l]; P.m[l] = m[l]; P.w[l] = w[l]; P.dw[l] = dw[l]; P.db[l] = db[l];
+    }
+    float* z = (float*)ws;
+    for (int l = 0; l < 4; ++l) { P.J[l] = J[l]; P.dz[l] = z; z += (size_t)n * J[l]; }
+    P.dcat = dcat; P.lddcat = lddcat; P.db5 = db5; P.voff = voff; P.n = n; P.K0 = K0; P.sync = sync;
+    GN_REQUIRE((K0 / 4 + KL - 1) / KL <= MLP_BLOCKS, GOALNET_E_SHAPE, "mlp_bwd: K0 too wide for one item per block");
+    hipStream_t st = (hipStream_t)stream;
+#define GN_MLP_BWD(MRV)                                                                                            \
+    {                                                                                                              \
+        const size_t a = (size_t)512 * MRV * sizeof(float), bb = (size_t)256 * MRV * sizeof(float4);               \
+        hipLaunchKernelGGL(mlp_bwd_kernel<MRV>, dim3(MLP_BLOCKS), dim3(256), a > bb ? a : bb, st, P);              \
+    }
+    switch (rows_class(n)) {
+        case 4: GN_MLP_BWD(4) break;
+        case 8: GN_MLP_BWD(8) break;
+        case 12: GN_MLP_BWD(12) break;
+        default: GN_MLP_BWD(16) break;
+    }
+#undef GN_MLP_BWD
+    GN_LAUNCH_CHECK("mlp_bwd");
+    return 0;
+}
+
+}  // extern "C"

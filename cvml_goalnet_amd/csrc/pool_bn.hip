@@ -86,90 +86,10 @@ __device__ __forceinline__ double column_sum16(const double* __restrict__ col0, 
     return t;
 }
 
-// column_sum16's summation tree walked by ONE thread (same bits): the fused small-shape kernels below finalise inside the
-// producing launch, where a single block (the last to arrive) owns all C columns
-__device__ __forceinline__ double column_sum16_serial(const double* __restrict__ col0, int nparts, int64_t stride) {
-    double t = 0.0;
-    for (int pg = 0; pg < 16; ++pg) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int pt = pg;
-        for (; pt + 48 < nparts; pt += 64) {
-            a0 += col0[(int64_t)pt * stride];
-            a1 += col0[(int64_t)(pt + 16) * stride];
-            a2 += col0[(int64_t)(pt + 32) * stride];
-            a3 += col0[(int64_t)(pt + 48) * stride];
-        }
-        for (; pt < nparts; pt += 16) a0 += col0[(int64_t)pt * stride];
-        t += (a0 + a1) + (a2 + a3);
-    }
-    return t;
-}
-
-// Ticket for "the last block finalises": every block calls it after its partial row is written. Release (the row reaches
-// device scope: L2 write-back on the multi-XCD part), ticket, and for the last block an acquire. The counter must be zero on
-// entry and is zero again on exit (the same contract as EpiP::tile_ctr, gemm_common.h). Returns true in the last block.
-__device__ __forceinline__ bool last_block_ticket(int* ctr, int nblocks) {
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = atomicAdd(ctr, 1);
-        s_last = old == nblocks - 1;
-        if (s_last) *ctr = 0;
-    }
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last) __threadfence();
-    return last;
-}
-
-// what the small-shape kernels append to their launch (ctr == nullptr: nothing, the separate finalise kernels run)
-struct BnFin {          // forward: goalnet_bn_finalize's arguments
-    int* ctr; const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps; double count;
-    float* mean; float* invstd; float* scale; float* shift;
-};
-struct BnBwdFin {       // backward reduce: goalnet_bn_bwd_finalize's arguments (mean / invstd are the kernel's own)
-    int* ctr; const float* gamma; double count; float* dgamma; float* dbeta; float* coef3;
-};
-struct DbiasFin { int* ctr; float* dbias; };       // fused backward: goalnet_partials_sum of the conv bias gradient
-
-__device__ __forceinline__ void bn_finalize_one(int c, double s, double q, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                                float momentum, float eps, double count, float* mean, float* invstd, float* scale, float* shift) {
-    const double m = s / count;
-    double var = q / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const float fm = (float)m;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    mean[c] = fm;
-    invstd[c] = is;
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - fm * sc;
-    if (rmean) {
-        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    }
-}
-
-__device__ __forceinline__ void bn_bwd_finalize_one(int c, int C, double s, double q, const float* gamma, const float* mean, const float* invstd,
-                                                    double count, float* dgamma, float* dbeta, float* coef3) {
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
-    // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
-    const double a = (double)gamma[c] * (double)invstd[c];
-    const double m1 = s / count, m2 = q / count;
-    const double b = -a * m2 * (double)invstd[c];
-    const double cc = -a * m1 - b * (double)mean[c];
-    coef3[c] = (float)a;
-    coef3[C + c] = (float)b;
-    coef3[2 * C + c] = (float)cc;
-}
-
 // max_pool2d CPU kernel), partial sums of p and p*p per channel.
 __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __restrict__ y, float* __restrict__ p,
                                                               uint8_t* __restrict__ idx, double* __restrict__ partials,
-                                                              int N, int Hc, int Wc, int C, BnFin fin) {
+                                                              int N, int Hc, int Wc, int C) {
     __shared__ double smem[256 * 8];
     const int tid = threadIdx.x;
     const int G = C >> 2;                 // channel groups of 4; G divides 256
@@ -207,12 +127,24 @@ __global__ __launch_bounds__(256) void pool_bnstats_fwd_kernel(const float* __re
         acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
     }
     block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
-    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
-        for (int c = tid; c < C; c += 256) {
-            const double s = column_sum16_serial(partials + c, gridDim.x, 2 * C);
-            const double q = column_sum16_serial(partials + C + c, gridDim.x, 2 * C);
-            bn_finalize_one(c, s, q, fin.gamma, fin.beta, fin.rmean, fin.rvar, fin.momentum, fin.eps, fin.count, fin.mean, fin.invstd, fin.scale, fin.shift);
-        }
+}
+
+__device__ __forceinline__ void bn_finalize_one(int c, double s, double q, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                                float momentum, float eps, double count, float* mean, float* invstd, float* scale, float* shift) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = fm;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - fm * sc;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
 }
 
@@ -257,7 +189,7 @@ __device__ __forceinline__ float4 dz4_of(const h16raw& r) { return f4_of_h16(r.u
 template <typename DZ, typename PT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict__ dz, const PT* __restrict__ p,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           double* __restrict__ partials, int64_t npix, int C, BnBwdFin fin) {
+                                                           double* __restrict__ partials, int64_t npix, int C) {
     __shared__ double smem[256 * 8];
     const int tid = threadIdx.x;
     const int G = C >> 2;
@@ -275,13 +207,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const DZ* __restrict
         acc[0][3] += (double)d.w; acc[1][3] += (double)d.w * (double)((x.w - mu.w) * is.w);
     }
     block_reduce_store<2>(acc, G, tid, smem, partials + (int64_t)blockIdx.x * 2 * C, C, C);
-    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
-        for (int c = tid; c < C; c += 256) {
-            const double s = column_sum16_serial(partials + c, gridDim.x, 2 * C);
-            const double q = column_sum16_serial(partials + C + c, gridDim.x, 2 * C);
-            bn_bwd_finalize_one(c, C, s, q, fin.gamma, mean, invstd, fin.count, fin.dgamma, fin.dbeta, fin.coef3);
-        }
-    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, const float* __restrict__ gamma,
@@ -293,7 +218,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const double s = column_sum16(partials + c, nparts, 2 * C, c < C, sm);
     const double q = column_sum16(partials + C + c, nparts, 2 * C, c < C, sm);
     if (c >= C || threadIdx.x >= 16) return;
-    bn_bwd_finalize_one(c, C, s, q, gamma, mean, invstd, count, dgamma, dbeta, coef3);
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    // dp = a*(dz - m1 - xhat*m2) = a*dz + b*p + cc,  xhat = (p - mean)*invstd
+    const double a = (double)gamma[c] * (double)invstd[c];
+    const double m1 = s / count, m2 = q / count;
+    const double b = -a * m2 * (double)invstd[c];
+    const double cc = -a * m1 - b * (double)mean[c];
+    coef3[c] = (float)a;
+    coef3[C + c] = (float)b;
+    coef3[2 * C + c] = (float)cc;
 }
 
 // ---- backward phase 3: dy[n,h,w,c] = relu'(y) * sum over the (<= 9) pooling windows that contain (h,w) and
@@ -301,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ p,
                                                         const uint8_t* __restrict__ idx,
                                                         const float* __restrict__ coef3, float* __restrict__ dy,
-                                                        double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C, DbiasFin fin) {
+                                                        double* __restrict__ dbias_partials, int N, int Hc, int Wc, int C) {
     __shared__ double smem[256 * 4];
     const int tid = threadIdx.x;
     const int G = C >> 2;
@@ -340,9 +274,152 @@ __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict
         accb[0][0] += (double)acc.x; accb[0][1] += (double)acc.y; accb[0][2] += (double)acc.z; accb[0][3] += (double)acc.w;
     }
     block_reduce_store<1>(accb, G, tid, smem, dbias_partials + (int64_t)blockIdx.x * C, C, C);
-    if (fin.ctr && last_block_ticket(fin.ctr, gridDim.x)) {
-        for (int c = tid; c < C; c += 256) fin.dbias[c] = (float)column_sum16_serial(dbias_partials + c, gridDim.x, C);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small shapes: one block = four channels x all pixels (see goalnet_pool_bn_fwd_small). Sums: every thread adds its pixels in
+// index order (fp64), the 64 lanes of a wave are added by xor-shuffles, the four wave totals in wave order: deterministic.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block totals of NV x 4 doubles per thread -> out[NV * 4] in LDS (valid for every thread after the call)
+constexpr int SMALL_T = 1024;        // threads per block: 16 waves x one pixel per lane keep ~1000 pixels' loads in flight
+template <int NV>
+__device__ __forceinline__ void block_totals(double (&v)[NV][4], double* red /* [16][NV * 4] */, double* out /* [NV * 4] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NV; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double t = wave_sum_d64(v[a][c]);
+            if (lane == 0) red[wv * (NV * 4) + a * 4 + c] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < NV * 4) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < SMALL_T / 64; ++w) t += red[w * (NV * 4) + threadIdx.x];
+        out[threadIdx.x] = t;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SMALL_T) void pool_bn_fwd_small_kernel(const float* __restrict__ y, float* __restrict__ p, uint8_t* __restrict__ idx,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                                               float* __restrict__ mean, float* __restrict__ invstd,
+                                                               float* __restrict__ scale, float* __restrict__ shift,
+                                                               int N, int Hc, int Wc, int C) {
+    __shared__ double red[(SMALL_T / 64) * 8], tot[8];
+    const int g4 = blockIdx.x * 4;                       // this block's four channels
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    const int fp = Hp * Wp, npix = N * fp;
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int pix = threadIdx.x; pix < npix; pix += SMALL_T) {
+        const int n = pix / fp, q = pix - n * fp;
+        const int ph = q / Wp, pw = q - ph * Wp;
+        const float* src = y + ((int64_t)(n * Hc + ph) * Wc + pw) * C + g4;
+        float4 v[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) v[kh * 3 + kw] = *reinterpret_cast<const float4*>(src + ((int64_t)kh * Wc + kw) * C);
+        float4 best = v[0];
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {                    // first maximum in (kh, kw) scan order, NaN wins: ATen's max_pool2d rule
+            if (v[k].x > best.x || v[k].x != v[k].x) { best.x = v[k].x; bi[0] = k; }
+            if (v[k].y > best.y || v[k].y != v[k].y) { best.y = v[k].y; bi[1] = k; }
+            if (v[k].z > best.z || v[k].z != v[k].z) { best.z = v[k].z; bi[2] = k; }
+            if (v[k].w > best.w || v[k].w != v[k].w) { best.w = v[k].w; bi[3] = k; }
+        }
+        *reinterpret_cast<float4*>(p + (int64_t)pix * C + g4) = best;
+        if (idx) *reinterpret_cast<uint32_t*>(idx + idx_off(n, q, g4, fp, C)) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
+        acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
+        acc[0][2] += (double)best.z; acc[1][2] += (double)best.z * (double)best.z;
+        acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
+    }
+    block_totals<2>(acc, red, tot);
+    if (threadIdx.x < 4) {
+        const int c = g4 + threadIdx.x;
+        bn_finalize_one(c, tot[threadIdx.x], tot[4 + threadIdx.x], gamma, beta, rmean, rvar, momentum, eps, (double)npix, mean, invstd, scale, shift);
+    }
+}
+
+// backward of one block in one launch: (sum dz, sum dz xhat) over the pooled pixels -> dgamma, dbeta and the coefficients of
+// dp = a dz + b p + cc -> dy = relu'(y) x (max-pool backward of dp) as a gather over the <= 9 windows of every conv pixel
+// (bnpool_bwd_kernel's arithmetic) -> conv bias gradient = sum of dy
+__global__ __launch_bounds__(SMALL_T) void bn_pool_bwd_small_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                               const uint8_t* __restrict__ idx, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dy, float* __restrict__ dbias,
+                                                               int N, int Hc, int Wc, int C) {
+    __shared__ double red[(SMALL_T / 64) * 8], tot[8];
+    __shared__ float coef[3][4];
+    const int g4 = blockIdx.x * 4;
+    const int Hp = Hc - 2, Wp = Wc - 2;
+    const int fp = Hp * Wp, npool = N * fp;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + g4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + g4);
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int pix = threadIdx.x; pix < npool; pix += SMALL_T) {
+        const float4 d = *reinterpret_cast<const float4*>(dz + (int64_t)pix * C + g4);
+        const float4 x = *reinterpret_cast<const float4*>(p + (int64_t)pix * C + g4);
+        acc[0][0] += (double)d.x; acc[1][0] += (double)d.x * (double)((x.x - mu.x) * is.x);
+        acc[0][1] += (double)d.y; acc[1][1] += (double)d.y * (double)((x.y - mu.y) * is.y);
+        acc[0][2] += (double)d.z; acc[1][2] += (double)d.z * (double)((x.z - mu.z) * is.z);
+        acc[0][3] += (double)d.w; acc[1][3] += (double)d.w * (double)((x.w - mu.w) * is.w);
+    }
+    block_totals<2>(acc, red, tot);
+    if (threadIdx.x < 4) {
+        const int c = g4 + threadIdx.x;
+        const double s = tot[threadIdx.x], q = tot[4 + threadIdx.x], count = (double)npool;
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        const double a = (double)gamma[c] * (double)invstd[c];
+        const double m1 = s / count, m2 = q / count;
+        const double b = -a * m2 * (double)invstd[c];
+        coef[0][threadIdx.x] = (float)a;
+        coef[1][threadIdx.x] = (float)b;
+        coef[2][threadIdx.x] = (float)(-a * m1 - b * (double)mean[c]);
+    }
+    __syncthreads();
+    const float4 ca = make_float4(coef[0][0], coef[0][1], coef[0][2], coef[0][3]);
+    const float4 cb = make_float4(coef[1][0], coef[1][1], coef[1][2], coef[1][3]);
+    const float4 cc = make_float4(coef[2][0], coef[2][1], coef[2][2], coef[2][3]);
+    const int fc = Hc * Wc, nconv = N * fc;
+    double accb[1][4] = {{0, 0, 0, 0}};
+    for (int pix = threadIdx.x; pix < nconv; pix += SMALL_T) {
+        const int n = pix / fc, q = pix - n * fc;
+        const int h = q / Wc, w = q - h * Wc;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int ph = h - dh, pw = w - dw;                 // window origin; this pixel is tap (dh, dw)
+                const bool ok = (unsigned)ph < (unsigned)Hp && (unsigned)pw < (unsigned)Wp;
+                const int phc = ok ? ph : 0, pwc = ok ? pw : 0;     // clamped: loads stay unconditional
+                const int64_t o = ((int64_t)(n * Hp + phc) * Wp + pwc) * C + g4;
+                const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + idx_off(n, phc * Wp + pwc, g4, fp, C));
+                const float4 d = *reinterpret_cast<const float4*>(dz + o);
+                const float4 x = *reinterpret_cast<const float4*>(p + o);
+                const unsigned k = dh * 3 + dw;
+                a4.x += (ok && (ii & 0xffu) == k && x.x > 0.f) ? fmaf(ca.x, d.x, fmaf(cb.x, x.x, cc.x)) : 0.f;
+                a4.y += (ok && ((ii >> 8) & 0xffu) == k && x.y > 0.f) ? fmaf(ca.y, d.y, fmaf(cb.y, x.y, cc.y)) : 0.f;
+                a4.z += (ok && ((ii >> 16) & 0xffu) == k && x.z > 0.f) ? fmaf(ca.z, d.z, fmaf(cb.z, x.z, cc.z)) : 0.f;
+                a4.w += (ok && (ii >> 24) == k && x.w > 0.f) ? fmaf(ca.w, d.w, fmaf(cb.w, x.w, cc.w)) : 0.f;
+            }
+        *reinterpret_cast<float4*>(dy + (int64_t)pix * C + g4) = a4;
+        accb[0][0] += (double)a4.x; accb[0][1] += (double)a4.y; accb[0][2] += (double)a4.z; accb[0][3] += (double)a4.w;
+    }
+    block_totals<1>(accb, red, tot);
+    if (threadIdx.x < 4) dbias[g4 + threadIdx.x] = (float)tot[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -917,7 +994,7 @@ int goalnet_pool_bnstats_fwd(const float* y, float* p, uint8_t* idx, double* par
         const size_t need = lds < 16384 ? 16384 : lds;      // the fp64 block reduction reuses the buffer (256 x 8 doubles)
         launch_pool_fwd_v2<float, float>(nparts, need, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     } else {
-        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C, BnFin{});
+        hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("pool_bnstats_fwd");
     return 0;
@@ -969,7 +1046,7 @@ int goalnet_bn_bwd_reduce(const float* dz, const float* p, const float* mean, co
     GN_REQUIRE(npix > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce: bad dims");
     GN_PARTS_OK("bn_bwd_reduce");
     GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce: alignment");
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C, BnBwdFin{});
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C);
     GN_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
@@ -985,13 +1062,13 @@ int goalnet_bn_bwd_reduce_t(const void* dz, int dz_bf16, const void* p, int p_bf
     hipStream_t st = (hipStream_t)stream;
     typedef __hip_bfloat16 bf;
     typedef _Float16 hf;
-    if (f16 && dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, hf>), grid, block, 0, st, (const hf*)dz, (const hf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else if (f16 && dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, float>), grid, block, 0, st, (const hf*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else if (f16 && p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, hf>), grid, block, 0, st, (const float*)dz, (const hf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C, BnBwdFin{});
-    else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C, BnBwdFin{});
+    if (f16 && dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, hf>), grid, block, 0, st, (const hf*)dz, (const hf*)p, mean, invstd, partials, npix, C);
+    else if (f16 && dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<hf, float>), grid, block, 0, st, (const hf*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    else if (f16 && p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, hf>), grid, block, 0, st, (const float*)dz, (const hf*)p, mean, invstd, partials, npix, C);
+    else if (dz_bf16 && p_bf16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, bf>), grid, block, 0, st, (const bf*)dz, (const bf*)p, mean, invstd, partials, npix, C);
+    else if (dz_bf16)      hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf, float>), grid, block, 0, st, (const bf*)dz, (const float*)p, mean, invstd, partials, npix, C);
+    else if (p_bf16)       hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, bf>), grid, block, 0, st, (const float*)dz, (const bf*)p, mean, invstd, partials, npix, C);
+    else                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), grid, block, 0, st, (const float*)dz, (const float*)p, mean, invstd, partials, npix, C);
     GN_LAUNCH_CHECK("bn_bwd_reduce_t");
     return 0;
 }
@@ -1020,7 +1097,7 @@ int goalnet_bnpool_bwd(const float* dz, const float* p, const uint8_t* idx, cons
         launch_bnpool_bwd_v2<float, float>(nparts, need, (hipStream_t)stream, dz, p, idx, coef3, dy, (__hip_bfloat16*)nullptr, dbias_partials, N, Hc, Wc, C);
     } else {
         hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
-                           dbias_partials, N, Hc, Wc, C, DbiasFin{});
+                           dbias_partials, N, Hc, Wc, C);
     }
     GN_LAUNCH_CHECK("bnpool_bwd");
     return 0;
@@ -1071,49 +1148,34 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
     return 0;
 }
 
-/* ---- small shapes (the reference's 10-frame sub-batches at 40 x 40, main.py:177-196): the direct kernels with the finalise
- * step folded in — the last block to arrive sums the partial rows in goalnet_bn_finalize's order and writes what the separate
- * finalise launch would (same bits), so each BatchNorm / pool pass is ONE launch. ctr: one int32, zero on entry, zero on exit. */
-int goalnet_pool_bn_fwd_fused(const float* y, float* p, uint8_t* idx, double* partials, int nparts, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, int64_t count,
-                              float* mean, float* invstd, float* scale, float* shift, int* ctr,
+/* ---- small shapes (the reference's 10-frame sub-batches at 40 x 40, main.py:177-196): channel-sliced kernels. One block owns
+ * four channels and walks ALL pixels, so its per-channel sums are complete inside the block: no partial rows, no finalise
+ * launch, and the backward does reduce -> coefficients -> max-pool / ReLU backward -> bias gradient in one launch. */
+int goalnet_pool_bn_fwd_small(const float* y, float* p, uint8_t* idx, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* mean, float* invstd, float* scale, float* shift,
                               int N, int Hc, int Wc, int C, void* stream) {
-    GN_REQUIRE(y && p && partials && gamma && beta && mean && invstd && scale && shift && ctr, GOALNET_E_NULL, "pool_bn_fwd_fused: null pointer");
-    GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "pool_bn_fwd_fused: running stats must both be set or both NULL");
-    GN_PARTS_OK("pool_bn_fwd_fused");
-    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && count > 0, GOALNET_E_SHAPE, "pool_bn_fwd_fused: need Hc, Wc >= 3");
-    GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bn_fwd_fused: C=%d must be 4*2^k, <= 1024", C);
+    GN_REQUIRE(y && p && gamma && beta && mean && invstd && scale && shift, GOALNET_E_NULL, "pool_bn_fwd_small: null pointer");
+    GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "pool_bn_fwd_small: running stats must both be set or both NULL");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && (int64_t)N * Hc * Wc < (1ll << 24), GOALNET_E_SHAPE, "pool_bn_fwd_small: need Hc, Wc >= 3 and < 2^24 pixels");
+    GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bn_fwd_small: C=%d must be 4*2^k, <= 1024", C);
     GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
-               "pool_bn_fwd_fused: pointers must be 16-byte aligned");
-    const BnFin fin{ctr, gamma, beta, running_mean, running_var, momentum, eps, (double)count, mean, invstd, scale, shift};
-    hipLaunchKernelGGL(pool_bnstats_fwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, y, p, idx, partials, N, Hc, Wc, C, fin);
-    GN_LAUNCH_CHECK("pool_bn_fwd_fused");
+               "pool_bn_fwd_small: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(pool_bn_fwd_small_kernel, dim3(C / 4), dim3(SMALL_T), 0, (hipStream_t)stream, y, p, idx, gamma, beta, running_mean,
+                       running_var, momentum, eps, mean, invstd, scale, shift, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("pool_bn_fwd_small");
     return 0;
 }
 
-int goalnet_bn_bwd_reduce_fused(const float* dz, const float* p, const float* mean, const float* invstd, double* partials, int nparts,
-                                int64_t npix, int C, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* coef3,
-                                int* ctr, void* stream) {
-    GN_REQUIRE(dz && p && mean && invstd && partials && gamma && dgamma && dbeta && coef3 && ctr, GOALNET_E_NULL, "bn_bwd_reduce_fused: null pointer");
-    GN_REQUIRE(npix > 0 && count > 0 && chan_ok(C), GOALNET_E_SHAPE, "bn_bwd_reduce_fused: bad dims");
-    GN_PARTS_OK("bn_bwd_reduce_fused");
-    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(mean) && aligned16(invstd), GOALNET_E_ALIGN, "bn_bwd_reduce_fused: alignment");
-    const BnBwdFin fin{ctr, gamma, (double)count, dgamma, dbeta, coef3};
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, float>), dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, mean, invstd, partials, npix, C, fin);
-    GN_LAUNCH_CHECK("bn_bwd_reduce_fused");
-    return 0;
-}
-
-int goalnet_bnpool_bwd_fused(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, double* dbias_partials,
-                             int nparts, float* dbias, int* ctr, int N, int Hc, int Wc, int C, void* stream) {
-    GN_REQUIRE(dz && p && idx && coef3 && dy && dbias_partials && dbias && ctr, GOALNET_E_NULL, "bnpool_bwd_fused: null pointer");
-    GN_PARTS_OK("bnpool_bwd_fused");
-    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && chan_ok(C), GOALNET_E_SHAPE, "bnpool_bwd_fused: bad dims");
-    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) &&
-               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_fused: alignment");
-    hipLaunchKernelGGL(bnpool_bwd_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, dz, p, idx, coef3, dy,
-                       dbias_partials, N, Hc, Wc, C, DbiasFin{ctr, dbias});
-    GN_LAUNCH_CHECK("bnpool_bwd_fused");
+int goalnet_bn_pool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* mean, const float* invstd,
+                              const float* gamma, float* dgamma, float* dbeta, float* dy, float* dbias,
+                              int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && idx && mean && invstd && gamma && dgamma && dbeta && dy && dbias, GOALNET_E_NULL, "bn_pool_bwd_small: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && (int64_t)N * Hc * Wc < (1ll << 24) && chan_ok(C), GOALNET_E_SHAPE, "bn_pool_bwd_small: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bn_pool_bwd_small: alignment");
+    hipLaunchKernelGGL(bn_pool_bwd_small_kernel, dim3(C / 4), dim3(SMALL_T), 0, (hipStream_t)stream, dz, p, idx, mean, invstd, gamma, dgamma,
+                       dbeta, dy, dbias, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bn_pool_bwd_small");
     return 0;
 }
 

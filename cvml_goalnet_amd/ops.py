@@ -187,42 +187,31 @@ def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C)
                                          _f16(dypad), _s()), "bnpool_bwd_bf16p")
 
 
-SMALL_BN_ELEMS = 1 << 22       # conv outputs up to this many elements take the one-launch pool / BatchNorm kernels
+SMALL_BN_PIXELS = 8192        # conv outputs of up to this many pixels (N x Hc x Wc) take the one-launch channel-sliced pool / BatchNorm kernels
 
 
-def pool_bn_fwd_fused(y, p, idx, partials, gamma, beta, rmean, rvar, momentum, eps, count, st, N, Hc, Wc, C):
+def pool_bn_fwd_small(y, p, idx, gamma, beta, rmean, rvar, momentum, eps, st, N, Hc, Wc, C):
     """pool_bnstats_fwd + bn_finalize in one launch (small fp32 shapes); st = (4, C): mean, invstd, scale, shift"""
-    _chk(y, p, idx, partials, gamma, beta, rmean, rvar, st)
+    _chk(y, p, idx, gamma, beta, rmean, rvar, st)
     _req(y.dtype == F32 and p.dtype == F32 and y.numel() == N * Hc * Wc * C and p.numel() == N * (Hc - 2) * (Wc - 2) * C,
-         "pool_bn_fwd_fused: fp32 y (N,Hc,Wc,C) and p (N,Hc-2,Wc-2,C)")
-    _req(idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel()), "pool_bn_fwd_fused: idx must be uint8, one per pooled element")
-    _req(st.numel() == 4 * C and st.is_contiguous(), "pool_bn_fwd_fused: st must be (4, C)")
-    ctr = _tile_counters(("pool_bn_fwd", N, Hc, Wc, C), y.device)
-    check(lib().goalnet_pool_bn_fwd_fused(y.data_ptr(), p.data_ptr(), _p(idx), partials.data_ptr(), _rows(partials, 2 * C), gamma.data_ptr(),
-                                          beta.data_ptr(), _p(rmean), _p(rvar), momentum, eps, count, st[0].data_ptr(), st[1].data_ptr(),
-                                          st[2].data_ptr(), st[3].data_ptr(), ctr.data_ptr(), N, Hc, Wc, C, _s()), "pool_bn_fwd_fused")
+         "pool_bn_fwd_small: fp32 y (N,Hc,Wc,C) and p (N,Hc-2,Wc-2,C)")
+    _req(idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel()), "pool_bn_fwd_small: idx must be uint8, one per pooled element")
+    _req(st.numel() == 4 * C and st.is_contiguous(), "pool_bn_fwd_small: st must be (4, C)")
+    check(lib().goalnet_pool_bn_fwd_small(y.data_ptr(), p.data_ptr(), _p(idx), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar),
+                                          momentum, eps, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                          N, Hc, Wc, C, _s()), "pool_bn_fwd_small")
 
 
-def bn_bwd_reduce_fused(dz, p, mean, invstd, partials, npix, C, gamma, count, dgamma, dbeta, coef3):
-    """bn_bwd_reduce + bn_bwd_finalize in one launch (small fp32 shapes)"""
-    _chk(dz, p, mean, invstd, partials, gamma, dgamma, dbeta, coef3)
-    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == npix * C, "bn_bwd_reduce_fused: fp32 dz / p of npix * C elements")
-    _req(coef3.numel() == 3 * C and dgamma.numel() == C and dbeta.numel() == C, "bn_bwd_reduce_fused: coef3 (3 C), dgamma (C), dbeta (C)")
-    ctr = _tile_counters(("bn_bwd_reduce", npix, C), dz.device)
-    check(lib().goalnet_bn_bwd_reduce_fused(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
-                                            _rows(partials, 2 * C), npix, C, gamma.data_ptr(), count, dgamma.data_ptr(), dbeta.data_ptr(),
-                                            coef3.data_ptr(), ctr.data_ptr(), _s()), "bn_bwd_reduce_fused")
-
-
-def bnpool_bwd_fused(dz, p, idx, coef3, dy, dbias_partials, dbias, N, Hc, Wc, C):
-    """bnpool_bwd + the conv bias gradient's partials_sum in one launch (small fp32 shapes)"""
-    _chk(dz, p, idx, coef3, dy, dbias_partials, dbias)
+def bn_pool_bwd_small(dz, p, idx, mean, invstd, gamma, dgamma, dbeta, dy, dbias, N, Hc, Wc, C):
+    """bn_bwd_reduce + bn_bwd_finalize + bnpool_bwd + the conv bias gradient in one launch (small fp32 shapes)"""
+    _chk(dz, p, idx, mean, invstd, gamma, dgamma, dbeta, dy, dbias)
     npool = N * (Hc - 2) * (Wc - 2) * C
-    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C and dbias.numel() == C,
-         "bnpool_bwd_fused: fp32 dz / p / idx of the pooled shape, dy of the conv shape, dbias (C)")
-    ctr = _tile_counters(("bnpool_bwd", N, Hc, Wc, C), dz.device)
-    check(lib().goalnet_bnpool_bwd_fused(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), dbias_partials.data_ptr(),
-                                         _rows(dbias_partials, C), dbias.data_ptr(), ctr.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd_fused")
+    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C,
+         "bn_pool_bwd_small: fp32 dz / p / idx of the pooled shape, dy of the conv shape")
+    _req(dgamma.numel() == C and dbeta.numel() == C and dbias.numel() == C, "bn_pool_bwd_small: dgamma, dbeta, dbias (C)")
+    check(lib().goalnet_bn_pool_bwd_small(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                          dgamma.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), dbias.data_ptr(), N, Hc, Wc, C, _s()),
+          "bn_pool_bwd_small")
 
 
 def partials_sum(partials, nparts, stride, C, out):
@@ -514,6 +503,61 @@ def relu_bwd(dy, y, dz):
     _req(dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel(), "relu_bwd: argument check failed: dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel()")
     check(lib().goalnet_relu_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _s()), "relu_bwd")
     return dz
+
+
+MLP_WIDTHS = (512, 512, 256, 128)
+
+
+def _ptrs(ts):
+    return (ctypes.c_void_p * len(ts))(*[_p(t) for t in ts])
+
+
+def mlp_fwd(cat, ws, bs, masks, hs, mults, logit, out):
+    """fusion.0 .. fusion.12 + Sigmoid + 4y+1 on <= 16 rows in one launch. cat (n, K0) may be a view with a row stride;
+    ws / bs: 5 weights / biases; masks: 4 dropout multipliers or None; hs: 4 outputs; mults: 4 saved multipliers or None"""
+    _chk(cat, logit, out, *ws, *bs, *masks, *hs, *mults)
+    n, K0 = cat.shape
+    _req(len(ws) == 5 and len(bs) == 5 and len(masks) == 4 and len(hs) == 4 and len(mults) == 4, "mlp_fwd: 5 layers, 4 hidden outputs")
+    for l, wd in enumerate(MLP_WIDTHS):
+        kin = K0 if l == 0 else MLP_WIDTHS[l - 1]
+        _req(ws[l].numel() == wd * kin and bs[l].numel() == wd and hs[l].shape == (n, wd) and hs[l].is_contiguous(), f"mlp_fwd: layer {l} shapes")
+        _req(masks[l] is None or masks[l].shape == (n, wd), f"mlp_fwd: mask {l} shape")
+        _req(mults[l] is None or (mults[l].shape == (n, wd) and mults[l].is_contiguous()), f"mlp_fwd: mult {l} shape")
+    _req(ws[4].numel() == 128 and bs[4].numel() == 1 and logit.numel() == n and out.numel() == n, "mlp_fwd: head shapes")
+    ldm = (ctypes.c_int64 * 4)(*[0 if m is None else _ld(m) for m in masks])
+    sync = _tile_counters(("mlp_fwd", n, K0), cat.device)
+    check(lib().goalnet_mlp_fwd(cat.data_ptr(), _ld(cat), K0, _ptrs(ws), _ptrs(bs), _ptrs(masks), ldm, _ptrs(hs), _ptrs(mults),
+                                logit.data_ptr(), out.data_ptr(), n, sync.data_ptr(), _s()), "mlp_fwd")
+
+
+def mlp_bwd(dout, out, xs, ms, ws, dws, dbs, dcat, db5, voff):
+    """backward of mlp_fwd in one launch. xs: cat (view), h1..h4; ms: mcat (view), mult1..4; dws / dbs: 5 gradient slots;
+    dcat (n, K0) contiguous; db5 (K0 - voff) or None."""
+    _chk(dout, out, dcat, db5, *xs, *ms, *ws, *dws, *dbs)
+    n, K0 = xs[0].shape
+    _req(len(xs) == 5 and len(ms) == 5 and len(ws) == 5 and len(dws) == 5 and len(dbs) == 5, "mlp_bwd: 5 layers")
+    _req(dout.numel() == n and out.numel() == n and dout.is_contiguous() and out.is_contiguous(), "mlp_bwd: dout / out (n)")
+    _req(dcat.shape == (n, K0) and dcat.is_contiguous() and (db5 is None or db5.numel() == K0 - voff), "mlp_bwd: dcat (n, K0), db5 (K0 - voff)")
+    for l in range(1, 5):
+        _req(xs[l].shape == (n, MLP_WIDTHS[l - 1]) and xs[l].is_contiguous() and (ms[l] is None or (ms[l].shape == xs[l].shape and ms[l].is_contiguous())),
+             f"mlp_bwd: layer {l} input / multiplier shapes")
+    for l in range(5):
+        _req(dws[l].numel() == ws[l].numel() and dws[l].is_contiguous() and dbs[l].is_contiguous(), f"mlp_bwd: layer {l} gradient slots")
+    nbytes = lib().goalnet_mlp_bwd_ws_bytes(n)
+    wsb = torch.empty(nbytes // 4, dtype=F32, device=dout.device)
+    sync = _tile_counters(("mlp_bwd", n, K0), dout.device)
+    check(lib().goalnet_mlp_bwd(dout.data_ptr(), out.data_ptr(), _ptrs(xs), _ld(xs[0]), _ptrs(ms), 0 if ms[0] is None else _ld(ms[0]),
+                                _ptrs(ws), _ptrs(dws), _ptrs(dbs), dcat.data_ptr(), _ld(dcat), _p(db5), voff, n, K0, wsb.data_ptr(), nbytes,
+                                sync.data_ptr(), _s()), "mlp_bwd")
+
+
+def mlp_sync_error(device, n, K0) -> bool:
+    """True when a grid barrier of the fused MLP kernels timed out on this device (one host read-back; tests)"""
+    bad = False
+    for name in ("mlp_fwd", "mlp_bwd"):
+        t = _TILE_CTR.get(((name, n, K0), device.index))
+        bad = bad or (t is not None and bool(t[2].item() != 0))
+    return bad
 
 
 def head_fwd(h, w, b, logit, out):

@@ -111,19 +111,18 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
                                int f16, void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
-/* Small shapes (the reference's 10-frame sub-batches, main.py:177-196): the pool / BatchNorm passes with their finalise step
- * folded in — the last block to arrive sums the partial rows in the order of goalnet_bn_finalize / goalnet_bn_bwd_finalize /
- * goalnet_partials_sum and writes what that separate launch would (same bits), so each pass is ONE launch. fp32 tensors.
- * ctr: one int32 in device memory, zero on entry, zero again on exit (lend it to later calls on the same stream only). */
-int goalnet_pool_bn_fwd_fused(const float* y, float* p, uint8_t* idx, double* partials, int nparts, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, int64_t count,
-                              float* mean, float* invstd, float* scale, float* shift, int* ctr,
+/* Small shapes (the reference's 10-frame sub-batches, main.py:177-196): channel-sliced forms of the passes above. One block
+ * owns four channels and walks all pixels, so its per-channel sums are complete inside the block (fp64, fixed order): no
+ * partial rows and no finalise launch. fp32 tensors, < 2^24 pixels.
+ * forward = goalnet_pool_bnstats_fwd + goalnet_bn_finalize in one launch;
+ * backward = goalnet_bn_bwd_reduce + _finalize + goalnet_bnpool_bwd + goalnet_partials_sum (dbias) in one launch. */
+int goalnet_pool_bn_fwd_small(const float* y, float* p, uint8_t* idx, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* mean, float* invstd, float* scale, float* shift,
                               int N, int Hc, int Wc, int C, void* stream);
-int goalnet_bn_bwd_reduce_fused(const float* dz, const float* p, const float* mean, const float* invstd, double* partials, int nparts,
-                                int64_t npix, int C, const float* gamma, int64_t count, float* dgamma, float* dbeta, float* coef3,
-                                int* ctr, void* stream);
-int goalnet_bnpool_bwd_fused(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, double* dbias_partials,
-                             int nparts, float* dbias, int* ctr, int N, int Hc, int Wc, int C, void* stream);
+int goalnet_bn_pool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* mean, const float* invstd,
+                              const float* gamma, float* dgamma, float* dbeta, float* dy, float* dbias,
+                              int N, int Hc, int Wc, int C, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
  * (ddp.SyncStats; SURVEY.md §8(e) "SyncBN": all-reduce of per-channel sum(x), sum(x^2)) */
 int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream);
@@ -241,6 +240,24 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
                        int N, int Cin, int L, int Cout, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 /* dz = dy * (y > 0) */
 int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream);
+
+/* ---- the whole fusion MLP + head, and its backward, at <= 16 rows (the reference's sub-batches, main.py:177-184): ONE launch
+ * per direction (csrc/mlp.hip: 64 resident blocks walk the layers and meet at a bounded grid barrier between them).
+ * Pointer arrays are HOST arrays of device pointers, read at call time: w / b / dw / db [5] = fusion.0, .3, .6, .9, .12;
+ * mask / h / mult [4] = the dropout multipliers (nullable), outputs (n, 512 | 512 | 256 | 128, contiguous) and saved
+ * (pre-activation > 0) * mask (nullable) of fusion.0, .3, .6, .9. cat (n, K0) has row stride ldcat; K0 = 640 (audio) or 512.
+ * sync: int32[3] in device memory, zero on entry, zero again on exit ([2] is set, and stays set, if the barrier timed out).
+ * Backward: x [5] = cat, h1..h4; m [5] = the saved multipliers of those (mcat with row stride ldmcat, then mult[0..3]);
+ * writes dw / db of the five layers, dcat (n, K0) = the gradient wrt the pre-activations behind `cat`, and (db5 nullable)
+ * the column sums of dcat[:, voff:] = visbl.linear5.bias's gradient. ws: goalnet_mlp_bwd_ws_bytes(n). */
+int goalnet_mlp_blocks(void);
+int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const* w, const float* const* b,
+                    const float* const* mask, const int64_t* ldmask, float* const* h, float* const* mult,
+                    float* logit, float* out, int n, int* sync, void* stream);
+size_t goalnet_mlp_bwd_ws_bytes(int n);
+int goalnet_mlp_bwd(const float* dout, const float* out, const float* const* x, int64_t ldcat, const float* const* m, int64_t ldmcat,
+                    const float* const* w, float* const* dw, float* const* db, float* dcat, int64_t lddcat, float* db5, int voff,
+                    int n, int K0, void* ws, size_t ws_bytes, int* sync, void* stream);
 
 /* ---- head: fusion.12 (128 -> 1), Sigmoid, 4*y + 1.  utils.py:255-256, 270 ----------------------- */
 int goalnet_head_fwd(const float* h, int64_t ldh, const float* w, const float* b, float* logit, float* out,
