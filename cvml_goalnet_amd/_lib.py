@@ -32,6 +32,7 @@ PROTOTYPES = {
     "goalnet_dropout_mask": (c_int, [P, c_int64, c_uint64, c_uint32, c_float, P]),
     "goalnet_transpose_inner": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
     "goalnet_conv3x3_weight_flip": (c_int, [P, P, c_int, c_int, P]),
+    "goalnet_conv3x3_weight_flip2": (c_int, [P, P, c_int, c_int, P, P, c_int, c_int, P]),
     "goalnet_conv1_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "goalnet_conv1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "goalnet_conv1_wgrad": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
@@ -45,8 +46,10 @@ PROTOTYPES = {
     "goalnet_bnpool_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_bf16p_t": (c_int, [P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_pool_bn_fwd_small": (c_int, [P, P, P, P, P, P, P, c_float, c_float, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_bn_pool_bwd_small": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bn_small_ws_bytes": (c_size_t, [c_int]),
+    "goalnet_pool_bn_fwd_small": (c_int, [P, P, P, P, P, P, P, c_float, c_float, P, P, P, P, P, c_size_t, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bn_bwd_reduce_small": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_bnpool_bwd_small": (c_int, [P, P, P, P, P, P, P, c_size_t, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -87,9 +90,10 @@ PROTOTYPES = {
     "goalnet_conv1d_fwd": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_conv1d_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "goalnet_conv1d_bwd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "goalnet_conv1d_bwd_small": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_relu_bwd": (c_int, [P, P, P, c_int64, P]),
     "goalnet_mlp_blocks": (c_int, []),
-    "goalnet_mlp_fwd": (c_int, [P, c_int64, c_int, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "goalnet_mlp_fwd": (c_int, [P, c_int64, c_int, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
     "goalnet_mlp_bwd_ws_bytes": (c_size_t, [c_int]),
     "goalnet_mlp_bwd": (c_int, [P, P, P, c_int64, P, c_int64, P, P, P, P, c_int64, P, c_int, c_int, c_int, P, c_size_t, P, P]),
     "goalnet_head_fwd": (c_int, [P, c_int64, P, P, P, P, c_int, c_int, P]),
@@ -106,6 +110,7 @@ PROTOTYPES = {
     "goalnet_counter_add": (c_int, [P, c_int64, P]),
     "goalnet_dropout_masks_dev": (c_int, [P, c_int, ctypes.POINTER(c_int), c_int, c_uint64, c_uint32, c_uint32, P, c_float, c_int64, P]),
     "goalnet_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P]),
+    "goalnet_adam_step_dev_blocks": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, c_int, P]),
     "goalnet_adam_step_dev_shadow": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,
                                              c_int64, c_int, P]),
     "goalnet_adam_step_dev_guarded": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, P, c_int64, c_float, P, c_int64,

@@ -88,6 +88,21 @@ class _Fork:
         with torch.cuda.stream(self.side):
             return fn()
 
+    def run_marked(self, fn, *tensors):
+        """run(fn) and return an event recorded right behind it on the side stream (None when not forking): `wait(event)` makes
+        the current stream wait for THAT piece of side work only, not for everything the side stream holds"""
+        r = self.run(fn, *tensors)
+        if not self.enabled:
+            return r, None
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return r, ev
+
+    @staticmethod
+    def wait(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def join(self):
         if self.enabled and self.forked:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -185,6 +200,8 @@ class AVM(nn.Module):
         self.last_ctx = None
         self.last_used_w5b = False
         self._side_stream = None
+        self._adam_stream = None
+        self._fused_loss, self._fused_loss_done = None, False      # train_step -> forward_device: (labels, loss, dout) for the fused MLP launch
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
         # GOALNET_OVERLAP_LARGE=1: fork at every size AND run the fused Adam over linear5.weight on the side stream as soon as its
@@ -542,7 +559,7 @@ class AVM(nn.Module):
 
     def _small_bn(self, a, b, n, hc, wc, c):
         """the one-launch pool / BatchNorm kernels (csrc/pool_bn.hip, goalnet_*_fused): fp32 tensors, local statistics, few elements"""
-        return (a.dtype == F32 and b.dtype == F32 and self.stat_sync is None and n * hc * wc <= ops.SMALL_BN_PIXELS
+        return (a.dtype == F32 and b.dtype == F32 and self.stat_sync is None and c <= 512 and n * hc * wc * c <= ops.SMALL_BN_ELEMS
                 and os.environ.get("GOALNET_SMALL_BN", "1") != "0")
 
     def _bn_block(self, y, n, hc, wc, c, i, save, p16=False):
@@ -688,8 +705,10 @@ class AVM(nn.Module):
                 ms.append(torch.empty(n, width, dtype=F32, device=dev) if save else None)
             logit = torch.empty(n, dtype=F32, device=dev)
             out = torch.empty(n, dtype=F32, device=dev)
+            fl = self._fused_loss                    # train_step: the broadcast MSE rides in the same launch
             ops.mlp_fwd(cat, [P(f"fusion.{k}.weight") for k in keys], [P(f"fusion.{k}.bias") for k in keys], masks[1:5],
-                        hs[1:], ms[1:], logit, out)
+                        hs[1:], ms[1:], logit, out, *(fl if fl is not None else (None, None, None)))
+            self._fused_loss_done = fl is not None
             x = hs[4]
         for li, (key, width) in enumerate(() if fused_mlp else (("0", 512), ("3", 512), ("6", 256), ("9", 128))):
             hnext = torch.empty(n, width, dtype=F32, device=dev)
@@ -723,10 +742,22 @@ class AVM(nn.Module):
         npix = n * (hc - 2) * (wc - 2)
         small = self._small_bn(dbn, p, n, hc, wc, c) and not (self._half and i > 1)
         if small:
-            # the reference's operating point: BatchNorm backward, max-pool / ReLU backward and the bias gradient in ONE launch
+            # the reference's operating point: reduce + finalise in one launch (csrc/pool_bn.hip "small shapes"), then the rolling-row
+            # max-pool / ReLU backward (measured faster at this size than the one-launch 9-window gather: 14 against 35 us) with its
+            # bias-gradient row sum on the side stream
+            coef3 = torch.empty(3 * c, dtype=F32, device=dev)
+            ops.bn_bwd_reduce_small(dbn, p, st[0], st[1], self._pflat(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.weight"),
+                                    G(f"visbl.bnorm{i}.bias"), coef3, n, hc, wc, c)
             dy = torch.empty(n, hc, wc, c, dtype=F32, device=dev)
-            ops.bn_pool_bwd_small(dbn, p, idx, st[0], st[1], self._pflat(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.weight"),
-                                  G(f"visbl.bnorm{i}.bias"), dy, G(f"visbl.conv{i}.bias"), n, hc, wc, c)
+            if os.environ.get("GOALNET_SMALL_BNPOOL", "0") == "1":
+                ops.bnpool_bwd_small(dbn, p, idx, coef3, dy, G(f"visbl.conv{i}.bias"), n, hc, wc, c)
+                return dy
+            dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)
+            ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
+            if i == 1:
+                ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
+            else:
+                self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
             return dy
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
@@ -780,6 +811,15 @@ class AVM(nn.Module):
                 fork.join()                     # the bucket's gradients may have been written on the side stream
                 on_bucket(k)
 
+        # the data gradients of conv3 / conv2 read the weights flipped (csrc/layout.hip); the flips depend on nothing but the
+        # weights, so in a small step both go out FIRST, in one launch on the side stream, off the dX chain
+        wt3 = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
+        wt2 = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
+        flips_ev = None
+        flips_early = fork.enabled
+        if flips_early:
+            _, flips_ev = fork.run_marked(lambda: ops.conv3x3_weight_flip2(P("visbl.conv3.weight"), wt3, 512, 256,
+                                                                          P("visbl.conv2.weight"), wt2, 256, 64), wt3, wt2)
         # head + fusion MLP (reverse of utils.py:242-258)
         fused_mlp = self._mlp_fused(n) and ms[0] is not None
         dz = torch.empty(n, hs[0].shape[1] if fused_mlp else 128, dtype=F32, device=dev)
@@ -811,8 +851,13 @@ class AVM(nn.Module):
                 ops.linear_bwd_dw(dza, a2f, G("audbl.linear3.weight"), db=G("audbl.linear3.bias"))
                 da2 = torch.empty(n, 128 * l2, dtype=F32, device=dev)
                 ops.linear_bwd_dx(dza, P("audbl.linear3.weight"), da2, mult=None)
-                ops.relu_bwd(da2, a2f, da2)
                 da1 = torch.empty(n, 64, l1, dtype=F32, device=dev)
+                if n < 64:
+                    # few frames: each Conv1d layer's backward is one launch, its ReLU backward folded into the dz load
+                    ops.conv1d_bwd_small(ctx["a1"], da2, ctx["a2"], P("audbl.conv2.weight"), da1, G("audbl.conv2.weight"), G("audbl.conv2.bias"), n, 64, l1, 128)
+                    ops.conv1d_bwd_small(ctx["audio"], da1, ctx["a1"], P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
+                    return
+                ops.relu_bwd(da2, a2f, da2)
                 ops.conv1d_bwd(ctx["a1"], da2, P("audbl.conv2.weight"), da1, G("audbl.conv2.weight"), G("audbl.conv2.bias"), n, 64, l1, 128)
                 ops.relu_bwd(da1, ctx["a1"], da1)
                 ops.conv1d_bwd(ctx["audio"], da1, P("audbl.conv1.weight"), None, G("audbl.conv1.weight"), G("audbl.conv1.bias"), n, 30, bins, 64)
@@ -863,8 +908,11 @@ class AVM(nn.Module):
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
                                          ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
-        wt = torch.empty(512 * 9 * 256, dtype=F32, device=dev)
-        ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
+        wt = wt3
+        if flips_early:
+            fork.wait(flips_ev)
+        else:
+            ops.conv3x3_weight_flip(P("visbl.conv3.weight"), wt, 512, 256)
         o16_2 = dz16 and self._bwd16_ok(wp1) and ops.conv3x3_fwd_bf16p_o16_ok(n, hp2, wp2, 512, 256)
         dbn2 = torch.empty(n, hp2, wp2, 256, dtype=self._h16 if o16_2 else F32, device=dev)
         if self._half:
@@ -891,8 +939,9 @@ class AVM(nn.Module):
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
                                          ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
-        wt = torch.empty(256 * 9 * 64, dtype=F32, device=dev)
-        ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
+        wt = wt2
+        if not flips_early:
+            ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
         dbn1 = torch.empty(n, hp1, wp1, 64, dtype=F32, device=dev)
         if self._half:
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=self._h16, device=dev))
@@ -952,14 +1001,22 @@ class AVM(nn.Module):
         """main.py:187-193 on GPU tensors. Returns (loss (1,), pred (N,)) as GPU tensors, no host sync.
         `_loop_tick`: (frames, sub-batches) the caller's loop counters advance by (loop.VideoTrainer)."""
         self._defer_tick, self._pending_drop_tick = True, 0
+        n0 = visual.shape[0]
+        loss = torch.empty(1, dtype=F32, device=self._device)
+        dout = torch.empty(n0 if self.head == "regression" else (n0, self.num_classes), dtype=F32, device=self._device)
+        # the regression head's broadcast MSE is evaluated by the fused MLP launch itself where that launch exists (<= 16 rows)
+        lab32 = labels if (torch.is_tensor(labels) and labels.dtype == F32 and labels.is_contiguous() and labels.is_cuda) else None
+        self._fused_loss = (lab32, loss, dout) if (self.stat_sync is None and lab32 is not None and self._mlp_fused(n0)) else None
+        self._fused_loss_done = False
         try:
             out, ctx = self.forward_device(audio, visual, save=True)
         finally:
             self._defer_tick = False
+            self._fused_loss = None
         n = out.shape[0]
-        loss = torch.empty(1, dtype=F32, device=self._device)
-        dout = torch.empty(out.shape, dtype=F32, device=self._device)
-        if self.head == "classifier":
+        if self._fused_loss_done:
+            pass
+        elif self.head == "classifier":
             if self.stat_sync is not None:
                 raise GoalnetError("global-batch mode is defined for the regression head's broadcast MSE only")
             ops.cross_entropy(out, labels.to(F32), loss, dout)          # main.py:69, 189: CrossEntropyLoss(pred, (labels-1).long())
@@ -981,14 +1038,32 @@ class AVM(nn.Module):
         # its Adam pass the moment its gradient exists and its last reader of the step (the data gradient) is enqueued — on the
         # side stream, i.e. 36 GB of HBM traffic under the MFMA-bound convolution gradients that follow instead of after them
         early = sync is None and self.precision != "fp16" and self.overlap_large and self._fork_ok(n)
+        # Small steps (the reference's 10-frame sub-batches): the same idea as a BACKGROUND pass — the update of linear5.weight (90 % of
+        # the step's 0.66 GB of optimizer traffic) on a third stream and on a bounded number of blocks. Built, bit-identical, and
+        # measured WITHOUT gain at any width (GOALNET_EARLY_ADAM_BLOCKS=64 / 128 / 256 / 512: 1 226 / 1 042 / 990 / 980 us per step
+        # against 836 us without): every kernel of the backward chain is a few dependent memory round trips, and each of them
+        # gets slower beside a stream that keeps the memory system busy. Off by default (0).
+        bg_blocks = int(os.environ.get("GOALNET_EARLY_ADAM_BLOCKS", "0"))      # measured: 836 us without, 980-1230 us with 64-512 blocks
+        early_bg = (not early and sync is None and self.precision == "fp32" and self._w5b is None and n <= self.overlap_rows
+                    and self._fork_ok(n) and bg_blocks > 0)
         done_early = []
 
         def early_adam(fork):
             s5 = self.spec("visbl.linear5.weight")
-            fork.run(lambda: self._adam_range(s5.offset, s5.offset + s5.numel, lr, betas, eps, 1.0 / lscale))
+            if early_bg:
+                if self._adam_stream is None:
+                    self._adam_stream = torch.cuda.Stream(device=self._device)
+                st = self._adam_stream
+                st.wait_stream(torch.cuda.current_stream())       # the data gradient (last reader of the weights) is enqueued
+                if fork.enabled:
+                    st.wait_stream(fork.side)                      # the weight gradient runs on the side stream
+                with torch.cuda.stream(st):
+                    self._adam_range(s5.offset, s5.offset + s5.numel, lr, betas, eps, 1.0 / lscale, max_blocks=bg_blocks)
+            else:
+                fork.run(lambda: self._adam_range(s5.offset, s5.offset + s5.numel, lr, betas, eps, 1.0 / lscale))
             done_early.append((s5.offset, s5.offset + s5.numel))
         self.backward_device(ctx, dout, on_bucket=(lambda k: sync.on_bucket(self, k)) if sync is not None else None,
-                             after_linear5=early_adam if early else None)
+                             after_linear5=early_adam if (early or early_bg) else None)
         scale = 1.0
         if sync is not None:
             scale = sync.finish(self)
@@ -1001,6 +1076,8 @@ class AVM(nn.Module):
             ops.grad_finite_check(self._garena[after:], self._state[0], self._guard[0], self._guard[1])
             guard = self._guard[0]
         self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard, _done=done_early)
+        if early_bg and done_early:
+            torch.cuda.current_stream().wait_stream(self._adam_stream)     # the background pass joins before the step count moves
         if guard is not None:
             # a step whose Adam was skipped is not counted (torch's GradScaler does not count it either): the retry runs under
             # the same step count; `_adam_t` on the host counts ATTEMPTED steps
@@ -1053,7 +1130,7 @@ class AVM(nn.Module):
             self._adam_segs = segs
         return segs
 
-    def _adam_range(self, lo, hi, lr, betas, eps, grad_scale):
+    def _adam_range(self, lo, hi, lr, betas, eps, grad_scale, max_blocks=0):
         """the fused Adam on arena[lo:hi] (unsharded optimizer state: moments live at the arena's offsets); refreshes the part of
         the 16-bit copy of linear5.weight that lies inside. The step counter is NOT advanced (train_step does that once)."""
         segs = self._adam_state()
@@ -1064,6 +1141,8 @@ class AVM(nn.Module):
         if self._w5b is not None and self._w5b_version == self._w5_version() and a < b:
             ops.adam_step_dev_shadow(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0],
                                      self._w5b[a - s5.offset:b - s5.offset], a - lo, grad_scale, step_bias=1)
+        elif max_blocks:
+            ops.adam_step_dev_blocks(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0], grad_scale, step_bias=1, max_blocks=max_blocks)
         else:
             ops.adam_step_dev(p, g, m, v, lr, betas[0], betas[1], eps, self._state[0], grad_scale, step_bias=1)
 

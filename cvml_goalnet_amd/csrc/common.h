@@ -39,6 +39,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + slot;
 }
 
+// ---- inter-block hand-over inside ONE launch (last-block finalisers, grid barriers) without flushing the L2 ----------------
+// The eight XCDs' L2s are not coherent with each other, so `__threadfence()` (an agent-scope release + acquire) compiles to
+// `buffer_wbl2 sc1` + `buffer_inv sc1`: a write-back and invalidation of the WHOLE L2 — measured ~30 us per use in the 10-frame
+// step, where a whole kernel otherwise takes 5. Data that another block of the same launch must see is instead written and read
+// with relaxed agent-scope atomics (`global_store / global_load ... sc1`: write-through / re-fetch of just those lines, coherent
+// by the memory model's definition), the writers wait for their stores to complete (vmcnt(0)) before the block's ticket / arrival
+// atomic goes out, and the readers issue their loads after they have seen it. No cache-wide operation anywhere.
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every thread of the block: my st_dev stores are complete; then the block meets (s_barrier)
+__device__ __forceinline__ void dev_stores_done_block() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+}
+// after the block has seen the other blocks' ticket / arrival: loads below this point stay below it
+__device__ __forceinline__ void dev_loads_after() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -46,9 +46,42 @@ __global__ __launch_bounds__(256) void weight_flip_kernel(const float* __restric
         if (ci0 + r < Cin && co0 + c < Cout) wt[((int64_t)(ci0 + r) * 9 + (8 - t)) * Cout + co0 + c] = tile[c][r];
 }
 
+// two weight tensors in one launch (the 10-frame step flips conv3's and conv2's weights in every backward): blocks
+// [0, tiles_a) serve the first, the rest the second
+__global__ __launch_bounds__(256) void weight_flip2_kernel(const float* __restrict__ wa, float* __restrict__ wta, int CoutA, int CinA, int tiles_a,
+                                                          const float* __restrict__ wb, float* __restrict__ wtb, int CoutB, int CinB) {
+    __shared__ float tile[32][33];
+    const bool first = (int)blockIdx.x < tiles_a;
+    const float* w = first ? wa : wb;
+    float* wt = first ? wta : wtb;
+    const int Cout = first ? CoutA : CoutB, Cin = first ? CinA : CinB;
+    const int b = first ? blockIdx.x : blockIdx.x - tiles_a;
+    const int t = blockIdx.y;
+    const int tiles_ci = (Cin + 31) / 32;
+    const int co0 = (b / tiles_ci) * 32, ci0 = (b % tiles_ci) * 32;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = r0; r < 32; r += 8)
+        tile[r][c] = (co0 + r < Cout && ci0 + c < Cin) ? w[((int64_t)(co0 + r) * 9 + t) * Cin + ci0 + c] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int r = r0; r < 32; r += 8)
+        if (ci0 + r < Cin && co0 + c < Cout) wt[((int64_t)(ci0 + r) * 9 + (8 - t)) * Cout + co0 + c] = tile[c][r];
+}
+
 }  // namespace
 
 extern "C" {
+
+int goalnet_conv3x3_weight_flip2(const float* wa, float* wta, int CoutA, int CinA, const float* wb, float* wtb, int CoutB, int CinB, void* stream) {
+    GN_REQUIRE(wa && wta && wb && wtb, GOALNET_E_NULL, "conv3x3_weight_flip2: null pointer");
+    GN_REQUIRE(CoutA > 0 && CinA > 0 && CoutB > 0 && CinB > 0 && (int64_t)CoutA * CinA * 9 < (1ll << 30) && (int64_t)CoutB * CinB * 9 < (1ll << 30),
+               GOALNET_E_SHAPE, "conv3x3_weight_flip2: bad dims");
+    const int ta = ((CoutA + 31) / 32) * ((CinA + 31) / 32), tb = ((CoutB + 31) / 32) * ((CinB + 31) / 32);
+    hipLaunchKernelGGL(weight_flip2_kernel, dim3(ta + tb, 9), dim3(256), 0, (hipStream_t)stream, wa, wta, CoutA, CinA, ta, wb, wtb, CoutB, CinB);
+    GN_LAUNCH_CHECK("conv3x3_weight_flip2");
+    return 0;
+}
 
 int goalnet_transpose_inner(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream) {
     GN_REQUIRE(src && dst, GOALNET_E_NULL, "transpose_inner: null pointer");

@@ -4,13 +4,15 @@
 // With 10 rows the five layers (640 -> 512 -> 512 -> 256 -> 128 -> 1, 3 MB of weights) are a chain of latency-bound weight
 // streams: as separate launches (csrc/skinny.hip: 6 forward, 12 backward) each costs its own launch gap and ramp although it
 // runs 4 - 8 us. Here 64 blocks stay resident and walk the layers together; between layers they meet at a grid barrier
-// (an arrival counter in device memory, release / acquire fences at agent scope: the layer's outputs are written by blocks on
-// other XCDs, whose L2 is not coherent with this one's). The barrier is bounded: a block that does not see the others
+// (an arrival counter in device memory; what crosses the barrier is written and read with agent-scope relaxed atomics,
+// common.h "inter-block hand-over": the other XCDs' L2s are not coherent with this one's and a fence would flush the whole
+// L2). The barrier is bounded: a block that does not see the others
 // arrive within ~1 s sets an error word and every block leaves — no wave can spin forever. 64 blocks of 256 threads are
 // always co-resident on 256 CUs, also beside other kernels of the step (side-stream work, graph branches).
 //
 // All sums run in a fixed order (deterministic); fp32 throughout, as the reference.
 #include "common.h"
+#include "mse.h"
 
 using namespace goalnet;
 
@@ -27,6 +29,7 @@ struct MlpFwdP {
     float* h[4];                                    // layer outputs (n, J[l]), contiguous
     float* mult[4];                                 // (pre-activation > 0) * mask, saved for backward (nullable)
     float* logit; float* out;                       // (n)
+    const float* labels; float* loss; float* dout;  // optional tail: the broadcast MSE of `out` against labels (n) and dL/dout
     int n; int J[4];
     int* sync;                                      // [0] arrivals, [1] departures, [2] error flag; zero on entry / exit
 };
@@ -46,64 +49,112 @@ struct MlpBwdP {
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// phase = 1, 2, ...: returns false when the other blocks did not arrive in time (the caller leaves at once)
-__device__ __forceinline__ bool grid_barrier(int* sync, int phase, int nblocks) {
+// phase = 1, 2, ...: returns false when the other blocks did not arrive in time (the caller leaves at once). What the blocks
+// hand to each other across the barrier is written with st_dev and read with ld_dev (common.h: no L2 flush).
+__device__ __forceinline__ void grid_arrive(int* sync) {
+    dev_stores_done_block();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool grid_wait(int* sync, int phase, int nblocks) {
     __shared__ int s_ok;
-    __threadfence();                       // release: this block's global writes of the phase
-    __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sync[0], 1);
         const int target = phase * nblocks;
         int spins = 0;
         while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < SPIN_LIMIT) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             ++spins;
         }
         s_ok = spins < SPIN_LIMIT;
-        if (!s_ok) sync[2] = 1;
+        if (!s_ok) __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    __threadfence();                       // acquire: the other blocks' writes
+    dev_loads_after();
     return s_ok != 0;
+}
+__device__ __forceinline__ bool grid_barrier(int* sync, int phase, int nblocks) {
+    grid_arrive(sync);
+    return grid_wait(sync, phase, nblocks);
 }
 
 // after the last phase: the last block to leave restores the counters for the next launch
 __device__ __forceinline__ void grid_leave(int* sync, int nblocks) {
     if (threadIdx.x == 0) {
-        const int old = atomicAdd(&sync[1], 1);
-        if (old == nblocks - 1) { sync[0] = 0; sync[1] = 0; }
+        const int old = __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nblocks - 1) {
+            __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
+// Per wave: layers 0 and 1 give it two columns, layer 2 one, layer 3 one for the first half of the waves. All of a wave's
+// weights (13 float4 per lane) are requested at kernel start — they depend on nothing — so that between two barriers only the
+// previous layer's activations have to arrive.
 template <int MR>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
     __shared__ __attribute__((aligned(16))) float xs[MR * KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int gw = blockIdx.x * 4 + wv, NW = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + wv, NW = gridDim.x * 4;          // 256 waves
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w0[2][3], w1[2][2], w2[2], w3;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int j = gw + c * NW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = lane * 4 + 256 * i;
+            w0[c][i] = (j < P.J[0] && k < P.K0) ? *reinterpret_cast<const float4*>(P.w[0] + (int64_t)j * P.K0 + k) : z4;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = lane * 4 + 256 * i;
+            w1[c][i] = (j < P.J[1] && k < P.J[0]) ? *reinterpret_cast<const float4*>(P.w[1] + (int64_t)j * P.J[0] + k) : z4;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = lane * 4 + 256 * i;
+        w2[i] = (gw < P.J[2] && k < P.J[1]) ? *reinterpret_cast<const float4*>(P.w[2] + (int64_t)gw * P.J[1] + k) : z4;
+    }
+    w3 = (gw < P.J[3] && lane * 4 < P.J[2]) ? *reinterpret_cast<const float4*>(P.w[3] + (int64_t)gw * P.J[2] + lane * 4) : z4;
+
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? P.K0 : P.J[l - 1];
-        const float* x = l == 0 ? P.x0 : P.h[l - 1];
-        const int64_t ldx = l == 0 ? P.ldx0 : (int64_t)K;
         const int J = P.J[l];
-        const float* W = P.w[l];
-        const int kq = K >> 2;
-        __syncthreads();                                       // xs of the previous layer has been read by every wave
-        for (int i = tid; i < MR * kq; i += 256) {
-            const int m = i / kq, q = i - m * kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < P.n) v = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + q * 4);
-            *reinterpret_cast<float4*>(&xs[m * KMAX + q * 4]) = v;
+        if (l == 0) {
+            const int kq = K >> 2;
+            for (int i = tid; i < MR * kq; i += 256) {
+                const int m = i / kq, q = i - m * kq;
+                *reinterpret_cast<float4*>(&xs[m * KMAX + q * 4]) = m < P.n ? *reinterpret_cast<const float4*>(P.x0 + (int64_t)m * P.ldx0 + q * 4) : z4;
+            }
+        } else {
+            __syncthreads();                                   // xs of the previous layer has been read by every wave
+            const float* x = P.h[l - 1];                       // written by other blocks of this launch: ld_dev
+            for (int i = tid; i < MR * K; i += 256) {
+                const int m = i / K, k = i - m * K;
+                xs[m * KMAX + k] = m < P.n ? ld_dev(x + (int64_t)m * K + k) : 0.f;
+            }
         }
         __syncthreads();
-        for (int j = gw; j < J; j += NW) {
+        const int ncols = l < 2 ? 2 : 1;
+        for (int c = 0; c < ncols; ++c) {
+            const int j = gw + c * NW;
+            if (j >= J) break;
             float acc[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const float4 w4 = *reinterpret_cast<const float4*>(W + (int64_t)j * K + k);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int k = lane * 4 + 256 * i;
+                if (k >= K) break;
+                float4 w4;
+                if (l == 0) w4 = c == 0 ? w0[0][i] : w0[1][i];
+                else if (l == 1) w4 = i < 2 ? (c == 0 ? w1[0][i] : w1[1][i]) : z4;
+                else if (l == 2) w4 = i < 2 ? w2[i] : z4;
+                else w4 = w3;
 #pragma unroll
                 for (int m = 0; m < MR; ++m) acc[m] += dot4(w4, *reinterpret_cast<const float4*>(&xs[m * KMAX + k]));
             }
@@ -118,31 +169,31 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
                 float g = v > 0.f ? 1.f : 0.f;
                 v = v > 0.f ? v : 0.f;
                 if (P.mask[l]) { const float mk = P.mask[l][(int64_t)lane * P.ldmask[l] + j]; v *= mk; g *= mk; }
-                P.h[l][(int64_t)lane * J + j] = v;
+                st_dev(&P.h[l][(int64_t)lane * J + j], v);           // the next layer's input, read by every block
                 if (P.mult[l]) P.mult[l][(int64_t)lane * J + j] = g;
             }
         }
-        if (l < 3 || blockIdx.x == 0) {
-            if (!grid_barrier(P.sync, l + 1, gridDim.x)) return;
-        } else {
-            // the head runs in block 0 only: the other blocks announce their layer-9 outputs and leave
-            __threadfence();
-            __syncthreads();
-            if (tid == 0) atomicAdd(&P.sync[0], 1);
-        }
+        grid_arrive(P.sync);
+        if (l == 3 && blockIdx.x != 0) break;                  // the head runs in block 0 only
+        if (!grid_wait(P.sync, l + 1, gridDim.x)) return;
     }
     if (blockIdx.x == 0) {
         // head (utils.py:255-256, 270): z = h4 . w12 + b12; out = 4 sigmoid(z) + 1. One wave per row.
         const int K = P.J[3];
         for (int m = wv; m < P.n; m += 4) {
             float acc = 0.f;
-            for (int k = lane; k < K; k += 64) acc = fmaf(P.h[3][(int64_t)m * K + k], P.w[4][k], acc);
+            for (int k = lane; k < K; k += 64) acc = fmaf(ld_dev(&P.h[3][(int64_t)m * K + k]), P.w[4][k], acc);
             acc = wave_sum_dpp(acc);
             if (lane == 0) {
                 const float z = acc + P.b[4][0];
                 P.logit[m] = z;
                 P.out[m] = 4.f / (1.f + expf(-z)) + 1.f;
             }
+        }
+        if (P.labels) {
+            // nn.MSELoss on (n,1) x (n,) (main.py:191) in the same launch: this block wrote every out[m] itself
+            __syncthreads();
+            mse_bcast_block(P.out, P.labels, P.n, P.loss, P.dout);
         }
     }
     grid_leave(P.sync, gridDim.x);
@@ -198,7 +249,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdP P) {
         } else {
             for (int i = tid; i < J * MR; i += 256) {
                 const int j = i / MR, m = i - j * MR;
-                sm[i] = m < P.n ? P.dz[l][(int64_t)m * J + j] : 0.f;
+                sm[i] = m < P.n ? ld_dev(&P.dz[l][(int64_t)m * J + j]) : 0.f;       // written by other blocks of this launch
             }
         }
         __syncthreads();
@@ -272,7 +323,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdP P) {
                         const float4 mv = *reinterpret_cast<const float4*>(mul + (int64_t)m * ldmul + k);
                         s.x *= mv.x; s.y *= mv.y; s.z *= mv.z; s.w *= mv.w;
                     }
-                    *reinterpret_cast<float4*>(dst + (int64_t)m * lddst + k) = s;
+                    float* o = dst + (int64_t)m * lddst + k;
+                    if (l > 0) { st_dev(o, s.x); st_dev(o + 1, s.y); st_dev(o + 2, s.z); st_dev(o + 3, s.w); }      // the next phase's g, read by every block
+                    else *reinterpret_cast<float4*>(o) = s;
                 } else {
                     s = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -309,7 +362,7 @@ int goalnet_mlp_blocks(void) { return MLP_BLOCKS; }
 
 int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const* w, const float* const* b,
                     const float* const* mask, const int64_t* ldmask, float* const* h, float* const* mult,
-                    float* logit, float* out, int n, int* sync, void* stream) {
+                    float* logit, float* out, const float* labels, float* loss, float* dout, int n, int* sync, void* stream) {
     GN_REQUIRE(cat && w && b && mask && ldmask && h && mult && logit && out && sync, GOALNET_E_NULL, "mlp_fwd: null pointer");
     GN_REQUIRE(n >= 1 && n <= 16, GOALNET_E_SHAPE, "mlp_fwd: 1..16 rows (the reference's sub-batches)");
     GN_REQUIRE(K0 > 0 && K0 <= KMAX && K0 % 4 == 0 && ldcat % 4 == 0 && aligned16(cat), GOALNET_E_SHAPE, "mlp_fwd: K0 must be a multiple of 4, <= 640");
@@ -324,7 +377,8 @@ int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const*
         GN_REQUIRE(h[l] && aligned16(h[l]), GOALNET_E_NULL, "mlp_fwd: null / misaligned output %d", l);
         P.mask[l] = mask[l]; P.ldmask[l] = ldmask[l]; P.h[l] = h[l]; P.mult[l] = mult[l]; P.J[l] = J[l];
     }
-    P.logit = logit; P.out = out; P.n = n; P.sync = sync;
+    GN_REQUIRE(!labels || (loss || dout), GOALNET_E_NULL, "mlp_fwd: labels without a loss / dout destination");
+    P.logit = logit; P.out = out; P.labels = labels; P.loss = loss; P.dout = dout; P.n = n; P.sync = sync;
     hipStream_t st = (hipStream_t)stream;
     switch (rows_class(n)) {
         case 4: hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;

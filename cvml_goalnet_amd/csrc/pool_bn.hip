@@ -277,51 +277,88 @@ __global__ __launch_bounds__(256) void bnpool_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// small shapes: one block = four channels x all pixels (see goalnet_pool_bn_fwd_small). Sums: every thread adds its pixels in
-// index order (fp64), the 64 lanes of a wave are added by xor-shuffles, the four wave totals in wave order: deterministic.
+// small shapes (the reference's 10-frame sub-batches at 40 x 40): every dependent round of memory accesses costs about a
+// microsecond there, so these kernels are built to need few of them. <= 32 blocks of 1024 threads walk the pixels in the
+// coalesced mapping of the first-generation kernels (lanes over channels, 16 bytes each; two to three pixels per thread), each
+// block writes ONE partial row, and the LAST block to arrive (a ticket counter, release / acquire fences) fetches the <= 32
+// rows of every column in a single batch of loads, adds them in row order and does the finalise step itself — what
+// goalnet_bn_finalize / goalnet_bn_bwd_finalize / goalnet_partials_sum do in a second launch.
+// (Round 3 measured the alternatives: a last block walking 80-256 partial rows serially, or one block per four channels
+// with 16-byte accesses 2 KB apart, were 3-5 x slower than the two-launch form)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum_d64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// block totals of NV x 4 doubles per thread -> out[NV * 4] in LDS (valid for every thread after the call)
-constexpr int SMALL_T = 1024;        // threads per block: 16 waves x one pixel per lane keep ~1000 pixels' loads in flight
+constexpr int SMALL_T = 1024;        // threads per block
+constexpr int SMALL_MAXB = 32;       // blocks = partial rows
+
+// threads with the same tid % G own the same four channels: their NV x 4 doubles are added in thread order and the threads
+// tid < G write row[a * stride + tid * 4 + c]. sm: SMALL_T * 4 doubles (32 KB), one pass per value.
 template <int NV>
-__device__ __forceinline__ void block_totals(double (&v)[NV][4], double* red /* [16][NV * 4] */, double* out /* [NV * 4] */) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__device__ __forceinline__ void small_block_row(double (&v)[NV][4], int G, double* sm, double* row, int stride) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int a = 0; a < NV; ++a)
+    for (int a = 0; a < NV; ++a) {
+        if (a) __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double t = wave_sum_d64(v[a][c]);
-            if (lane == 0) red[wv * (NV * 4) + a * 4 + c] = t;
+        for (int c = 0; c < 4; ++c) sm[tid * 4 + c] = v[a][c];
+        __syncthreads();
+        if (tid < G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double t = 0.0;
+                for (int q = tid; q < SMALL_T; q += G) t += sm[q * 4 + c];
+                st_dev(&row[a * stride + tid * 4 + c], t);        // read by the last block of this launch
+            }
         }
+    }
+}
+
+// Ticket: every block calls it after its partial row is written (st_dev: common.h "inter-block hand-over"). *ctr must be zero
+// on entry and is zero again on exit. Returns true in the last block to arrive.
+__device__ __forceinline__ bool last_block_ticket(int* ctr, int nblocks) {
+    __shared__ int s_last;
+    dev_stores_done_block();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == nblocks - 1;
+        if (s_last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
-    if (threadIdx.x < NV * 4) {
+    const bool last = s_last != 0;
+    if (last) dev_loads_after();
+    return last;
+}
+
+// last block: tot[col] = sum over the nb (<= SMALL_MAXB) partial rows of column col, rows in index order; all loads of a
+// column are issued before the first add. W columns, W doubles of LDS.
+__device__ __forceinline__ void small_column_totals(const double* __restrict__ partials, int nb, int W, double* tot) {
+    for (int col = threadIdx.x; col < W; col += SMALL_T) {
+        double v[SMALL_MAXB];
+#pragma unroll
+        for (int r = 0; r < SMALL_MAXB; ++r) v[r] = r < nb ? ld_dev(&partials[(int64_t)r * W + col]) : 0.0;
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < SMALL_T / 64; ++w) t += red[w * (NV * 4) + threadIdx.x];
-        out[threadIdx.x] = t;
+        for (int r = 0; r < SMALL_MAXB; ++r) t += v[r];
+        tot[col] = t;
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(SMALL_T) void pool_bn_fwd_small_kernel(const float* __restrict__ y, float* __restrict__ p, uint8_t* __restrict__ idx,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
-                                                               float* __restrict__ mean, float* __restrict__ invstd,
-                                                               float* __restrict__ scale, float* __restrict__ shift,
-                                                               int N, int Hc, int Wc, int C) {
-    __shared__ double red[(SMALL_T / 64) * 8], tot[8];
-    const int g4 = blockIdx.x * 4;                       // this block's four channels
+                                                                   double* __restrict__ partials, int* __restrict__ ctr,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                                                   float* __restrict__ scale, float* __restrict__ shift,
+                                                                   int N, int Hc, int Wc, int C) {
+    extern __shared__ double dsm[];                  // SMALL_T * 4 doubles (block reduction), then 2 C doubles (totals)
+    const int tid = threadIdx.x;
+    const int G = C >> 2, g = tid % G, pl = tid / G, ppi = SMALL_T / G;
     const int Hp = Hc - 2, Wp = Wc - 2;
     const int fp = Hp * Wp, npix = N * fp;
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int pix = threadIdx.x; pix < npix; pix += SMALL_T) {
+    for (int pix = blockIdx.x * ppi + pl; pix < npix; pix += gridDim.x * ppi) {
         const int n = pix / fp, q = pix - n * fp;
         const int ph = q / Wp, pw = q - ph * Wp;
-        const float* src = y + ((int64_t)(n * Hc + ph) * Wc + pw) * C + g4;
+        const float* src = y + ((int64_t)(n * Hc + ph) * Wc + pw) * C + g * 4;
         float4 v[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -336,65 +373,72 @@ __global__ __launch_bounds__(SMALL_T) void pool_bn_fwd_small_kernel(const float*
             if (v[k].z > best.z || v[k].z != v[k].z) { best.z = v[k].z; bi[2] = k; }
             if (v[k].w > best.w || v[k].w != v[k].w) { best.w = v[k].w; bi[3] = k; }
         }
-        *reinterpret_cast<float4*>(p + (int64_t)pix * C + g4) = best;
-        if (idx) *reinterpret_cast<uint32_t*>(idx + idx_off(n, q, g4, fp, C)) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        *reinterpret_cast<float4*>(p + (int64_t)pix * C + g * 4) = best;
+        if (idx) *reinterpret_cast<uint32_t*>(idx + idx_off(n, q, g * 4, fp, C)) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
         acc[0][0] += (double)best.x; acc[1][0] += (double)best.x * (double)best.x;
         acc[0][1] += (double)best.y; acc[1][1] += (double)best.y * (double)best.y;
         acc[0][2] += (double)best.z; acc[1][2] += (double)best.z * (double)best.z;
         acc[0][3] += (double)best.w; acc[1][3] += (double)best.w * (double)best.w;
     }
-    block_totals<2>(acc, red, tot);
-    if (threadIdx.x < 4) {
-        const int c = g4 + threadIdx.x;
-        bn_finalize_one(c, tot[threadIdx.x], tot[4 + threadIdx.x], gamma, beta, rmean, rvar, momentum, eps, (double)npix, mean, invstd, scale, shift);
-    }
+    small_block_row<2>(acc, G, dsm, partials + (int64_t)blockIdx.x * 2 * C, C);
+    if (!last_block_ticket(ctr, gridDim.x)) return;
+    small_column_totals(partials, gridDim.x, 2 * C, dsm);
+    for (int c = tid; c < C; c += SMALL_T)
+        bn_finalize_one(c, dsm[c], dsm[C + c], gamma, beta, rmean, rvar, momentum, eps, (double)npix, mean, invstd, scale, shift);
 }
 
-// backward of one block in one launch: (sum dz, sum dz xhat) over the pooled pixels -> dgamma, dbeta and the coefficients of
-// dp = a dz + b p + cc -> dy = relu'(y) x (max-pool backward of dp) as a gather over the <= 9 windows of every conv pixel
-// (bnpool_bwd_kernel's arithmetic) -> conv bias gradient = sum of dy
-__global__ __launch_bounds__(SMALL_T) void bn_pool_bwd_small_kernel(const float* __restrict__ dz, const float* __restrict__ p,
-                                                               const uint8_t* __restrict__ idx, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dy, float* __restrict__ dbias,
-                                                               int N, int Hc, int Wc, int C) {
-    __shared__ double red[(SMALL_T / 64) * 8], tot[8];
-    __shared__ float coef[3][4];
-    const int g4 = blockIdx.x * 4;
-    const int Hp = Hc - 2, Wp = Wc - 2;
-    const int fp = Hp * Wp, npool = N * fp;
-    const float4 mu = *reinterpret_cast<const float4*>(mean + g4);
-    const float4 is = *reinterpret_cast<const float4*>(invstd + g4);
+// backward, first launch: (sum dz, sum dz xhat) per channel -> dgamma, dbeta and the coefficients of dp = a dz + b p + cc
+__global__ __launch_bounds__(SMALL_T) void bn_bwd_reduce_small_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     double* __restrict__ partials, int* __restrict__ ctr,
+                                                                     const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta, float* __restrict__ coef3, int npix, int C) {
+    extern __shared__ double dsm[];
+    const int tid = threadIdx.x;
+    const int G = C >> 2, g = tid % G, pl = tid / G, ppi = SMALL_T / G;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + g * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + g * 4);
     double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int pix = threadIdx.x; pix < npool; pix += SMALL_T) {
-        const float4 d = *reinterpret_cast<const float4*>(dz + (int64_t)pix * C + g4);
-        const float4 x = *reinterpret_cast<const float4*>(p + (int64_t)pix * C + g4);
+    for (int pix = blockIdx.x * ppi + pl; pix < npix; pix += gridDim.x * ppi) {
+        const float4 d = *reinterpret_cast<const float4*>(dz + (int64_t)pix * C + g * 4);
+        const float4 x = *reinterpret_cast<const float4*>(p + (int64_t)pix * C + g * 4);
         acc[0][0] += (double)d.x; acc[1][0] += (double)d.x * (double)((x.x - mu.x) * is.x);
         acc[0][1] += (double)d.y; acc[1][1] += (double)d.y * (double)((x.y - mu.y) * is.y);
         acc[0][2] += (double)d.z; acc[1][2] += (double)d.z * (double)((x.z - mu.z) * is.z);
         acc[0][3] += (double)d.w; acc[1][3] += (double)d.w * (double)((x.w - mu.w) * is.w);
     }
-    block_totals<2>(acc, red, tot);
-    if (threadIdx.x < 4) {
-        const int c = g4 + threadIdx.x;
-        const double s = tot[threadIdx.x], q = tot[4 + threadIdx.x], count = (double)npool;
+    small_block_row<2>(acc, G, dsm, partials + (int64_t)blockIdx.x * 2 * C, C);
+    if (!last_block_ticket(ctr, gridDim.x)) return;
+    small_column_totals(partials, gridDim.x, 2 * C, dsm);
+    for (int c = tid; c < C; c += SMALL_T) {
+        const double s = dsm[c], q = dsm[C + c], count = (double)npix;
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         const double a = (double)gamma[c] * (double)invstd[c];
         const double m1 = s / count, m2 = q / count;
         const double b = -a * m2 * (double)invstd[c];
-        coef[0][threadIdx.x] = (float)a;
-        coef[1][threadIdx.x] = (float)b;
-        coef[2][threadIdx.x] = (float)(-a * m1 - b * (double)mean[c]);
+        coef3[c] = (float)a;
+        coef3[C + c] = (float)b;
+        coef3[2 * C + c] = (float)(-a * m1 - b * (double)mean[c]);
     }
-    __syncthreads();
-    const float4 ca = make_float4(coef[0][0], coef[0][1], coef[0][2], coef[0][3]);
-    const float4 cb = make_float4(coef[1][0], coef[1][1], coef[1][2], coef[1][3]);
-    const float4 cc = make_float4(coef[2][0], coef[2][1], coef[2][2], coef[2][3]);
+}
+
+// backward, second launch: dy = relu'(y) x (max-pool backward of dp) as a gather over the <= 9 windows of every conv pixel
+// (bnpool_bwd_kernel's arithmetic), and the conv bias gradient = sum of dy
+__global__ __launch_bounds__(SMALL_T) void bnpool_bwd_small_kernel(const float* __restrict__ dz, const float* __restrict__ p,
+                                                                  const uint8_t* __restrict__ idx, const float* __restrict__ coef3,
+                                                                  float* __restrict__ dy, double* __restrict__ partials, int* __restrict__ ctr,
+                                                                  float* __restrict__ dbias, int N, int Hc, int Wc, int C) {
+    extern __shared__ double dsm[];
+    const int tid = threadIdx.x;
+    const int G = C >> 2, g = tid % G, pl = tid / G, ppi = SMALL_T / G;
+    const int Hp = Hc - 2, Wp = Wc - 2, fp = Hp * Wp;
     const int fc = Hc * Wc, nconv = N * fc;
+    const float4 ca = *reinterpret_cast<const float4*>(coef3 + g * 4);
+    const float4 cb = *reinterpret_cast<const float4*>(coef3 + C + g * 4);
+    const float4 cc = *reinterpret_cast<const float4*>(coef3 + 2 * C + g * 4);
     double accb[1][4] = {{0, 0, 0, 0}};
-    for (int pix = threadIdx.x; pix < nconv; pix += SMALL_T) {
+    for (int pix = blockIdx.x * ppi + pl; pix < nconv; pix += gridDim.x * ppi) {
         const int n = pix / fc, q = pix - n * fc;
         const int h = q / Wc, w = q - h * Wc;
         float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -405,8 +449,8 @@ __global__ __launch_bounds__(SMALL_T) void bn_pool_bwd_small_kernel(const float*
                 const int ph = h - dh, pw = w - dw;                 // window origin; this pixel is tap (dh, dw)
                 const bool ok = (unsigned)ph < (unsigned)Hp && (unsigned)pw < (unsigned)Wp;
                 const int phc = ok ? ph : 0, pwc = ok ? pw : 0;     // clamped: loads stay unconditional
-                const int64_t o = ((int64_t)(n * Hp + phc) * Wp + pwc) * C + g4;
-                const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + idx_off(n, phc * Wp + pwc, g4, fp, C));
+                const int64_t o = ((int64_t)(n * Hp + phc) * Wp + pwc) * C + g * 4;
+                const uint32_t ii = *reinterpret_cast<const uint32_t*>(idx + idx_off(n, phc * Wp + pwc, g * 4, fp, C));
                 const float4 d = *reinterpret_cast<const float4*>(dz + o);
                 const float4 x = *reinterpret_cast<const float4*>(p + o);
                 const unsigned k = dh * 3 + dw;
@@ -415,11 +459,13 @@ __global__ __launch_bounds__(SMALL_T) void bn_pool_bwd_small_kernel(const float*
                 a4.z += (ok && ((ii >> 16) & 0xffu) == k && x.z > 0.f) ? fmaf(ca.z, d.z, fmaf(cb.z, x.z, cc.z)) : 0.f;
                 a4.w += (ok && (ii >> 24) == k && x.w > 0.f) ? fmaf(ca.w, d.w, fmaf(cb.w, x.w, cc.w)) : 0.f;
             }
-        *reinterpret_cast<float4*>(dy + (int64_t)pix * C + g4) = a4;
+        *reinterpret_cast<float4*>(dy + (int64_t)pix * C + g * 4) = a4;
         accb[0][0] += (double)a4.x; accb[0][1] += (double)a4.y; accb[0][2] += (double)a4.z; accb[0][3] += (double)a4.w;
     }
-    block_totals<1>(accb, red, tot);
-    if (threadIdx.x < 4) dbias[g4 + threadIdx.x] = (float)tot[threadIdx.x];
+    small_block_row<1>(accb, G, dsm, partials + (int64_t)blockIdx.x * C, C);
+    if (!last_block_ticket(ctr, gridDim.x)) return;
+    small_column_totals(partials, gridDim.x, C, dsm);
+    for (int c = tid; c < C; c += SMALL_T) dbias[c] = (float)dsm[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1148,34 +1194,60 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
     return 0;
 }
 
-/* ---- small shapes (the reference's 10-frame sub-batches at 40 x 40, main.py:177-196): channel-sliced kernels. One block owns
- * four channels and walks ALL pixels, so its per-channel sums are complete inside the block: no partial rows, no finalise
- * launch, and the backward does reduce -> coefficients -> max-pool / ReLU backward -> bias gradient in one launch. */
+/* ---- small shapes (the reference's 10-frame sub-batches at 40 x 40, main.py:177-196): see the kernels' comment. */
+static int small_blocks(int64_t pixels, int C) {
+    const int ppi = SMALL_T / (C >> 2);
+    int64_t nb = (pixels + 3 * ppi - 1) / (3 * ppi);          // about three pixels per thread
+    return nb < 1 ? 1 : nb > SMALL_MAXB ? SMALL_MAXB : (int)nb;
+}
+static bool small_ok(int N, int Hc, int Wc, int C) {
+    return chan_ok(C) && C <= 512 && (int64_t)N * Hc * Wc * C <= (1ll << 20);
+}
+
+size_t goalnet_bn_small_ws_bytes(int C) { return (size_t)SMALL_MAXB * 2 * C * sizeof(double); }
+
 int goalnet_pool_bn_fwd_small(const float* y, float* p, uint8_t* idx, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps,
                               float* mean, float* invstd, float* scale, float* shift,
-                              int N, int Hc, int Wc, int C, void* stream) {
-    GN_REQUIRE(y && p && gamma && beta && mean && invstd && scale && shift, GOALNET_E_NULL, "pool_bn_fwd_small: null pointer");
+                              void* ws, size_t ws_bytes, int* ctr, int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(y && p && gamma && beta && mean && invstd && scale && shift && ws && ctr, GOALNET_E_NULL, "pool_bn_fwd_small: null pointer");
     GN_REQUIRE((running_mean == nullptr) == (running_var == nullptr), GOALNET_E_NULL, "pool_bn_fwd_small: running stats must both be set or both NULL");
-    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && (int64_t)N * Hc * Wc < (1ll << 24), GOALNET_E_SHAPE, "pool_bn_fwd_small: need Hc, Wc >= 3 and < 2^24 pixels");
-    GN_REQUIRE(chan_ok(C), GOALNET_E_SHAPE, "pool_bn_fwd_small: C=%d must be 4*2^k, <= 1024", C);
-    GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN,
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && small_ok(N, Hc, Wc, C), GOALNET_E_SHAPE, "pool_bn_fwd_small: need Hc, Wc >= 3, C = 4*2^k <= 512, <= 2^20 elements");
+    GN_REQUIRE(aligned16(y) && aligned16(p) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0, GOALNET_E_ALIGN,
                "pool_bn_fwd_small: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(pool_bn_fwd_small_kernel, dim3(C / 4), dim3(SMALL_T), 0, (hipStream_t)stream, y, p, idx, gamma, beta, running_mean,
-                       running_var, momentum, eps, mean, invstd, scale, shift, N, Hc, Wc, C);
+    GN_REQUIRE(ws_bytes >= goalnet_bn_small_ws_bytes(C), GOALNET_E_WORKSPACE, "pool_bn_fwd_small: workspace too small");
+    const int nb = small_blocks((int64_t)N * (Hc - 2) * (Wc - 2), C);
+    hipLaunchKernelGGL(pool_bn_fwd_small_kernel, dim3(nb), dim3(SMALL_T), SMALL_T * 4 * sizeof(double), (hipStream_t)stream, y, p, idx,
+                       (double*)ws, ctr, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, N, Hc, Wc, C);
     GN_LAUNCH_CHECK("pool_bn_fwd_small");
     return 0;
 }
 
-int goalnet_bn_pool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* mean, const float* invstd,
-                              const float* gamma, float* dgamma, float* dbeta, float* dy, float* dbias,
-                              int N, int Hc, int Wc, int C, void* stream) {
-    GN_REQUIRE(dz && p && idx && mean && invstd && gamma && dgamma && dbeta && dy && dbias, GOALNET_E_NULL, "bn_pool_bwd_small: null pointer");
-    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && (int64_t)N * Hc * Wc < (1ll << 24) && chan_ok(C), GOALNET_E_SHAPE, "bn_pool_bwd_small: bad dims");
-    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, GOALNET_E_ALIGN, "bn_pool_bwd_small: alignment");
-    hipLaunchKernelGGL(bn_pool_bwd_small_kernel, dim3(C / 4), dim3(SMALL_T), 0, (hipStream_t)stream, dz, p, idx, mean, invstd, gamma, dgamma,
-                       dbeta, dy, dbias, N, Hc, Wc, C);
-    GN_LAUNCH_CHECK("bn_pool_bwd_small");
+int goalnet_bn_bwd_reduce_small(const float* dz, const float* p, const float* mean, const float* invstd, const float* gamma,
+                                float* dgamma, float* dbeta, float* coef3, void* ws, size_t ws_bytes, int* ctr,
+                                int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && mean && invstd && gamma && dgamma && dbeta && coef3 && ws && ctr, GOALNET_E_NULL, "bn_bwd_reduce_small: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && small_ok(N, Hc, Wc, C), GOALNET_E_SHAPE, "bn_bwd_reduce_small: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(coef3) && aligned16(mean) && aligned16(invstd) && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0,
+               GOALNET_E_ALIGN, "bn_bwd_reduce_small: alignment");
+    GN_REQUIRE(ws_bytes >= goalnet_bn_small_ws_bytes(C), GOALNET_E_WORKSPACE, "bn_bwd_reduce_small: workspace too small");
+    const int npool = N * (Hc - 2) * (Wc - 2);
+    hipLaunchKernelGGL(bn_bwd_reduce_small_kernel, dim3(small_blocks(npool, C)), dim3(SMALL_T), SMALL_T * 4 * sizeof(double), (hipStream_t)stream,
+                       dz, p, mean, invstd, (double*)ws, ctr, gamma, dgamma, dbeta, coef3, npool, C);
+    GN_LAUNCH_CHECK("bn_bwd_reduce_small");
+    return 0;
+}
+
+int goalnet_bnpool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, float* dbias,
+                             void* ws, size_t ws_bytes, int* ctr, int N, int Hc, int Wc, int C, void* stream) {
+    GN_REQUIRE(dz && p && idx && coef3 && dy && dbias && ws && ctr, GOALNET_E_NULL, "bnpool_bwd_small: null pointer");
+    GN_REQUIRE(N > 0 && Hc >= 3 && Wc >= 3 && small_ok(N, Hc, Wc, C), GOALNET_E_SHAPE, "bnpool_bwd_small: bad dims");
+    GN_REQUIRE(aligned16(dz) && aligned16(p) && aligned16(dy) && aligned16(coef3) &&
+               (reinterpret_cast<uintptr_t>(idx) & 3u) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0, GOALNET_E_ALIGN, "bnpool_bwd_small: alignment");
+    GN_REQUIRE(ws_bytes >= goalnet_bn_small_ws_bytes(C), GOALNET_E_WORKSPACE, "bnpool_bwd_small: workspace too small");
+    hipLaunchKernelGGL(bnpool_bwd_small_kernel, dim3(small_blocks((int64_t)N * Hc * Wc, C)), dim3(SMALL_T), SMALL_T * 4 * sizeof(double),
+                       (hipStream_t)stream, dz, p, idx, coef3, dy, (double*)ws, ctr, dbias, N, Hc, Wc, C);
+    GN_LAUNCH_CHECK("bnpool_bwd_small");
     return 0;
 }
 

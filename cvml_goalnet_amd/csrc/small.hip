@@ -9,6 +9,7 @@
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "mse.h"
 
 using namespace goalnet;
 
@@ -197,6 +198,94 @@ __global__ __launch_bounds__(256) void conv1d_db_kernel(const float* __restrict_
     if (threadIdx.x == 0) db[co] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- few frames (N < 64: the reference's 10-frame sub-batches): the whole backward of one Conv1d layer in ONE launch.
+// y (nullable) is the layer's own ReLU output: the effective output gradient is dz * (y > 0), so no separate ReLU-backward pass.
+// Blocks [0, nA): weight + bias gradient. A block owns 256 / Cin output channels x all Cin input channels, one (co, ci) pair
+// per thread; the gated dz rows of its channels sit in LDS, x is read through L1 / L2 (36 KB in all). Per frame the taps are
+// summed in fp32, across frames in fp64, frames in index order (conv1d_dw_kernel's arithmetic).
+// Blocks [nA, ...): data gradient, 16 lanes per output element splitting the output channels (conv1d_dx_kernel).
+__global__ __launch_bounds__(256) void conv1d_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                              const float* __restrict__ y, const float* __restrict__ w,
+                                                              float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                              int N, int Cin, int L, int Cout, int Lo, int stride, int pad, int nA) {
+    extern __shared__ float dzs[];                        // part A: [N][cpb][Lo]
+    if ((int)blockIdx.x < nA) {
+        const int cpb = 256 / Cin;
+        const int co0 = blockIdx.x * cpb;
+        const int tot = N * cpb * Lo;
+        for (int i = threadIdx.x; i < tot; i += 256) {
+            const int lo = i % Lo, cl = (i / Lo) % cpb, n = i / (Lo * cpb);
+            float v = 0.f;
+            if (co0 + cl < Cout) {
+                const int64_t o = ((int64_t)n * Cout + co0 + cl) * Lo + lo;
+                v = dz[o];
+                if (y && !(y[o] > 0.f)) v = 0.f;
+            }
+            dzs[i] = v;
+        }
+        __syncthreads();
+        const int cl = threadIdx.x / Cin, ci = threadIdx.x - cl * Cin;
+        if (cl < cpb && co0 + cl < Cout) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int n = 0; n < N; ++n) {
+                const float* xs = x + ((int64_t)n * Cin + ci) * L;
+                const float* ds = dzs + (n * cpb + cl) * Lo;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int lo = 0; lo < Lo; ++lo) {
+                    const float d = ds[lo];
+                    const int l0 = stride * lo - pad;
+                    if ((unsigned)(l0) < (unsigned)L) s0 = fmaf(d, xs[l0], s0);
+                    if ((unsigned)(l0 + 1) < (unsigned)L) s1 = fmaf(d, xs[l0 + 1], s1);
+                    if ((unsigned)(l0 + 2) < (unsigned)L) s2 = fmaf(d, xs[l0 + 2], s2);
+                }
+                a0 += s0; a1 += s1; a2 += s2;
+            }
+            float* o = dw + ((int64_t)(co0 + cl) * Cin + ci) * 3;
+            o[0] = (float)a0; o[1] = (float)a1; o[2] = (float)a2;
+        }
+        if ((int)threadIdx.x < cpb && co0 + (int)threadIdx.x < Cout) {
+            double a = 0.0;
+            for (int n = 0; n < N; ++n) {
+                const float* ds = dzs + (n * cpb + threadIdx.x) * Lo;
+                float t = 0.f;
+                for (int lo = 0; lo < Lo; ++lo) t += ds[lo];
+                a += t;
+            }
+            db[co0 + threadIdx.x] = (float)a;
+        }
+        return;
+    }
+    const int64_t total = (int64_t)N * Cin * L;
+    const int g = threadIdx.x & 15;
+    const int64_t step = (int64_t)(gridDim.x - nA) * 16;
+    const int64_t rounds = (total + step - 1) / step;
+    int64_t i = (int64_t)(blockIdx.x - nA) * 16 + (threadIdx.x >> 4);
+    for (int64_t r = 0; r < rounds; ++r, i += step) {
+        const bool ok = i < total;
+        const int64_t ic = ok ? i : 0;
+        const int l = (int)(ic % L);
+        const int ci = (int)((ic / L) % Cin);
+        const int64_t n = ic / ((int64_t)L * Cin);
+        const float* dzr = dz + n * Cout * Lo;
+        const float* yr = y ? y + n * Cout * Lo : nullptr;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = l + pad - k;
+            if (t < 0 || t % stride != 0) continue;
+            const int lo = t / stride;
+            if (lo >= Lo) continue;
+            for (int co = g; co < Cout; co += 16) {
+                float d = dzr[co * Lo + lo];
+                if (yr && !(yr[co * Lo + lo] > 0.f)) d = 0.f;
+                acc = fmaf(d, w[((int64_t)co * Cin + ci) * 3 + k], acc);
+            }
+        }
+        acc = row16_sum(acc);
+        if (ok && g == 0) dx[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dz, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -297,34 +386,7 @@ __global__ __launch_bounds__(1024) void head_bwd_dw_kernel(const float* __restri
 // loss = 1/n^2 sum_i sum_j (p_i - y_j)^2 = mean_i (p_i^2 - 2 p_i ybar + mean(y^2)); dpred_i = 2/n (p_i - ybar)
 __global__ __launch_bounds__(256) void mse_bcast_kernel(const float* __restrict__ pred, const float* __restrict__ labels, int N,
                                                        float* __restrict__ loss, float* __restrict__ dpred) {
-    __shared__ double red[3][4];
-    __shared__ double ybar_s;
-    double sy = 0.0, sy2 = 0.0, sp = 0.0, sp2 = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const double y = labels[i], p = pred[i];
-        sy += y; sy2 += y * y; sp += p; sp2 += p * p;
-    }
-    sy = wave_sum_d(sy); sy2 = wave_sum_d(sy2); sp = wave_sum_d(sp); sp2 = wave_sum_d(sp2);
-    __shared__ double r4[4][4];
-    if ((threadIdx.x & 63) == 0) {
-        const int wv = threadIdx.x >> 6;
-        r4[wv][0] = sy; r4[wv][1] = sy2; r4[wv][2] = sp; r4[wv][3] = sp2;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t[4];
-        for (int j = 0; j < 4; ++j) t[j] = r4[0][j] + r4[1][j] + r4[2][j] + r4[3][j];
-        const double n = (double)N;
-        const double ybar = t[0] / n;
-        ybar_s = ybar;
-        if (loss) loss[0] = (float)(t[3] / n - 2.0 * (t[2] / n) * ybar + t[1] / n);
-    }
-    __syncthreads();
-    (void)red;
-    if (dpred) {
-        const double ybar = ybar_s;
-        for (int i = threadIdx.x; i < N; i += 256) dpred[i] = (float)(2.0 / (double)N * ((double)pred[i] - ybar));
-    }
+    mse_bcast_block(pred, labels, N, loss, dpred);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,6 +529,25 @@ int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* d
     return 0;
 }
 
+/* goalnet_conv1d_bwd for few frames (N < 64) in ONE launch, with the ReLU backward of the layer's own output folded in:
+ * y (nullable) = the layer's ReLU output, effective dz = dz * (y > 0). dx nullable (first layer). Cin <= 256. */
+int goalnet_conv1d_bwd_small(const float* x, const float* dz, const float* y, const float* w, float* dx, float* dw, float* db,
+                             int N, int Cin, int L, int Cout, int stride, int pad, void* stream) {
+    GN_REQUIRE(x && dz && w && dw && db, GOALNET_E_NULL, "conv1d_bwd_small: null pointer");
+    GN_REQUIRE(N > 0 && N < 64 && Cin > 0 && Cin <= 256 && L > 0 && Cout > 0 && stride > 0 && pad >= 0 && L + 2 * pad >= 3, GOALNET_E_SHAPE,
+               "conv1d_bwd_small: bad dims (N < 64, Cin <= 256)");
+    const int Lo = (L + 2 * pad - 3) / stride + 1;
+    const int cpb = 256 / Cin;
+    const size_t lds = (size_t)N * cpb * Lo * sizeof(float);
+    GN_REQUIRE(lds <= 48 * 1024, GOALNET_E_SHAPE, "conv1d_bwd_small: the dz rows of a block do not fit LDS");
+    const int nA = (Cout + cpb - 1) / cpb;
+    const int nB = dx ? (int)grid1d((int64_t)N * Cin * L * 16) : 0;
+    hipLaunchKernelGGL(conv1d_bwd_small_kernel, dim3(nA + nB), dim3(256), lds, (hipStream_t)stream, x, dz, y, w, dx, dw, db,
+                       N, Cin, L, Cout, Lo, stride, pad, nA);
+    GN_LAUNCH_CHECK("conv1d_bwd_small");
+    return 0;
+}
+
 int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
     GN_REQUIRE(dy && y && dz, GOALNET_E_NULL, "relu_bwd: null pointer");
     GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "relu_bwd: bad count");
@@ -524,14 +605,27 @@ int goalnet_mse_bcast(const float* pred, const float* labels, int N, float* loss
 
 static int adam_launch(const char* who, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                        double beta2, double eps, const int64_t* step_dev, int64_t step_host, float grad_scale, void* stream,
-                       void* shadow = nullptr, int64_t sh_begin = 0, int64_t sh_count = 0, int sh_f16 = 0, const int64_t* bad_step = nullptr) {
+                       void* shadow = nullptr, int64_t sh_begin = 0, int64_t sh_count = 0, int sh_f16 = 0, const int64_t* bad_step = nullptr,
+                       int max_blocks = 8192) {
     GN_REQUIRE(p && g && m && v, GOALNET_E_NULL, "%s: null pointer", who);
     GN_REQUIRE(n > 0, GOALNET_E_SHAPE, "%s: bad count", who);
     GN_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), GOALNET_E_ALIGN, "%s: arenas must be 16-byte aligned", who);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2, max_blocks)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        (float)eps, step_dev, step_host, grad_scale, (uint2*)shadow, sh_begin >> 2, (sh_begin + sh_count) >> 2, sh_f16, bad_step);
     GN_LAUNCH_CHECK(who);
     return 0;
+}
+
+/* goalnet_adam_step_dev on at most max_blocks blocks of 256 threads: a BACKGROUND pass. The 10-frame step runs the update of
+ * linear5.weight (90 % of the bytes) on its own stream under the rest of backward; on the default 8192 blocks it takes every CU and
+ * all of the HBM bandwidth and the latency-bound kernels of the backward chain queue behind it, on ~128 blocks it streams at a
+ * third of the bandwidth and leaves the chain alone. */
+int goalnet_adam_step_dev_blocks(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                 double eps, const int64_t* step, int64_t step_bias, float grad_scale, int max_blocks, void* stream) {
+    GN_REQUIRE(step, GOALNET_E_NULL, "adam_step_dev_blocks: null pointer");
+    GN_REQUIRE(max_blocks >= 1 && max_blocks <= 65535, GOALNET_E_SHAPE, "adam_step_dev_blocks: 1..65535 blocks");
+    return adam_launch("adam_step_dev_blocks", p, g, m, v, n, lr, beta1, beta2, eps, step, step_bias, grad_scale, stream, nullptr, 0, 0, 0, nullptr,
+                       max_blocks);
 }
 
 int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

@@ -7,6 +7,7 @@ Tensors are fp32, on the GPU, in the device layouts named in the header (NHWC / 
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -79,6 +80,13 @@ def conv3x3_weight_flip(w, wt, cout, cin):
     _req(w.numel() == wt.numel() == cout * cin * 9, "conv3x3_weight_flip: argument check failed: w.numel() == wt.numel() == cout * cin * 9")
     check(lib().goalnet_conv3x3_weight_flip(w.data_ptr(), wt.data_ptr(), cout, cin, _s()), "conv3x3_weight_flip")
     return wt
+
+
+def conv3x3_weight_flip2(wa, wta, couta, cina, wb, wtb, coutb, cinb):
+    _chk(wa, wta, wb, wtb)
+    _req(wa.numel() == wta.numel() == couta * cina * 9 and wb.numel() == wtb.numel() == coutb * cinb * 9, "conv3x3_weight_flip2: sizes")
+    check(lib().goalnet_conv3x3_weight_flip2(wa.data_ptr(), wta.data_ptr(), couta, cina, wb.data_ptr(), wtb.data_ptr(), coutb, cinb, _s()),
+          "conv3x3_weight_flip2")
 
 
 def conv1_fwd(x_nchw, w, b, y, N, H, W):
@@ -187,7 +195,7 @@ def bnpool_bwd_bf16p(dz, p, idx, coef3, dy, dypad, dbias_partials, N, Hc, Wc, C)
                                          _f16(dypad), _s()), "bnpool_bwd_bf16p")
 
 
-SMALL_BN_PIXELS = 8192        # conv outputs of up to this many pixels (N x Hc x Wc) take the one-launch channel-sliced pool / BatchNorm kernels
+SMALL_BN_ELEMS = 1 << 20       # conv outputs of up to this many elements (C <= 512) take the small-shape pool / BatchNorm kernels
 
 
 def pool_bn_fwd_small(y, p, idx, gamma, beta, rmean, rvar, momentum, eps, st, N, Hc, Wc, C):
@@ -197,21 +205,39 @@ def pool_bn_fwd_small(y, p, idx, gamma, beta, rmean, rvar, momentum, eps, st, N,
          "pool_bn_fwd_small: fp32 y (N,Hc,Wc,C) and p (N,Hc-2,Wc-2,C)")
     _req(idx is None or (idx.dtype == torch.uint8 and idx.numel() == p.numel()), "pool_bn_fwd_small: idx must be uint8, one per pooled element")
     _req(st.numel() == 4 * C and st.is_contiguous(), "pool_bn_fwd_small: st must be (4, C)")
+    nbytes = lib().goalnet_bn_small_ws_bytes(C)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=y.device)
+    ctr = _tile_counters(("pool_bn_fwd", N, Hc, Wc, C), y.device)
     check(lib().goalnet_pool_bn_fwd_small(y.data_ptr(), p.data_ptr(), _p(idx), gamma.data_ptr(), beta.data_ptr(), _p(rmean), _p(rvar),
                                           momentum, eps, st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
-                                          N, Hc, Wc, C, _s()), "pool_bn_fwd_small")
+                                          ws.data_ptr(), nbytes, ctr.data_ptr(), N, Hc, Wc, C, _s()), "pool_bn_fwd_small")
 
 
-def bn_pool_bwd_small(dz, p, idx, mean, invstd, gamma, dgamma, dbeta, dy, dbias, N, Hc, Wc, C):
-    """bn_bwd_reduce + bn_bwd_finalize + bnpool_bwd + the conv bias gradient in one launch (small fp32 shapes)"""
-    _chk(dz, p, idx, mean, invstd, gamma, dgamma, dbeta, dy, dbias)
+def bn_bwd_reduce_small(dz, p, mean, invstd, gamma, dgamma, dbeta, coef3, N, Hc, Wc, C):
+    """bn_bwd_reduce + bn_bwd_finalize in one launch (small fp32 shapes)"""
+    _chk(dz, p, mean, invstd, gamma, dgamma, dbeta, coef3)
     npool = N * (Hc - 2) * (Wc - 2) * C
-    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C,
-         "bn_pool_bwd_small: fp32 dz / p / idx of the pooled shape, dy of the conv shape")
-    _req(dgamma.numel() == C and dbeta.numel() == C and dbias.numel() == C, "bn_pool_bwd_small: dgamma, dbeta, dbias (C)")
-    check(lib().goalnet_bn_pool_bwd_small(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                          dgamma.data_ptr(), dbeta.data_ptr(), dy.data_ptr(), dbias.data_ptr(), N, Hc, Wc, C, _s()),
-          "bn_pool_bwd_small")
+    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == npool, "bn_bwd_reduce_small: fp32 dz / p of the pooled shape")
+    _req(dgamma.numel() == C and dbeta.numel() == C and coef3.numel() == 3 * C, "bn_bwd_reduce_small: dgamma, dbeta (C), coef3 (3 C)")
+    nbytes = lib().goalnet_bn_small_ws_bytes(C)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dz.device)
+    ctr = _tile_counters(("bn_bwd_reduce", N, Hc, Wc, C), dz.device)
+    check(lib().goalnet_bn_bwd_reduce_small(dz.data_ptr(), p.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(),
+                                            dbeta.data_ptr(), coef3.data_ptr(), ws.data_ptr(), nbytes, ctr.data_ptr(), N, Hc, Wc, C, _s()),
+          "bn_bwd_reduce_small")
+
+
+def bnpool_bwd_small(dz, p, idx, coef3, dy, dbias, N, Hc, Wc, C):
+    """bnpool_bwd + the conv bias gradient in one launch (small fp32 shapes; a direct 9-window gather)"""
+    _chk(dz, p, idx, coef3, dy, dbias)
+    npool = N * (Hc - 2) * (Wc - 2) * C
+    _req(dz.dtype == F32 and p.dtype == F32 and dz.numel() == p.numel() == idx.numel() == npool and dy.numel() == N * Hc * Wc * C and dbias.numel() == C,
+         "bnpool_bwd_small: fp32 dz / p / idx of the pooled shape, dy of the conv shape, dbias (C)")
+    nbytes = lib().goalnet_bn_small_ws_bytes(C)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dz.device)
+    ctr = _tile_counters(("bnpool_bwd", N, Hc, Wc, C), dz.device)
+    check(lib().goalnet_bnpool_bwd_small(dz.data_ptr(), p.data_ptr(), idx.data_ptr(), coef3.data_ptr(), dy.data_ptr(), dbias.data_ptr(),
+                                         ws.data_ptr(), nbytes, ctr.data_ptr(), N, Hc, Wc, C, _s()), "bnpool_bwd_small")
 
 
 def partials_sum(partials, nparts, stride, C, out):
@@ -228,6 +254,10 @@ def partials_sum_f64(partials, C, out):
 
 
 N_TILE_CTR = 1024
+# The fused split-K reduction (the last block of a tile sums its slabs) is built and tested, and OFF by default: one block summing
+# 13 slabs x 64 KB is a chain of ~50 dependent memory round trips (measured on the 10-frame step: +450 us per step against the
+# separate reduce launch, which spreads the same bytes over every CU and costs 1.6 us of launch gap inside a graph)
+FUSED_SPLITK = os.environ.get("GOALNET_FUSED_SPLITK", "0") == "1"
 _TILE_CTR = {}
 _WGRAD_CODES = {}
 
@@ -250,9 +280,9 @@ def conv3x3_fwd(x, scale, shift, w, bias, relu, y, N, H, W, Cin, Cout):
     _req(bias is None or bias.numel() == Cout, "conv3x3_fwd: argument check failed: bias is None or bias.numel() == Cout")
     nbytes = lib().goalnet_conv3x3_fwd_ws_bytes(N, H, W, Cin, Cout)       # > 0 only for small N (split-K slabs)
     ws = torch.empty(nbytes // 4, dtype=F32, device=x.device) if nbytes else None
-    ctr = _tile_counters(("conv3x3_fwd", N, H, W, Cin, Cout, scale is None), x.device) if nbytes else None
+    ctr = _tile_counters(("conv3x3_fwd", N, H, W, Cin, Cout, scale is None), x.device) if (nbytes and FUSED_SPLITK) else None
     check(lib().goalnet_conv3x3_fwd(x.data_ptr(), _p(scale), _p(shift), w.data_ptr(), _p(bias), int(relu), y.data_ptr(),
-                                    N, H, W, Cin, Cout, _p(ws), nbytes, _p(ctr), N_TILE_CTR if nbytes else 0, _s()), "conv3x3_fwd")
+                                    N, H, W, Cin, Cout, _p(ws), nbytes, _p(ctr), N_TILE_CTR if ctr is not None else 0, _s()), "conv3x3_fwd")
     return y
 
 
@@ -269,9 +299,9 @@ def conv3x3_wgrad(x, scale, shift, dy, dw, N, H, W, Cin, Cout):
         check(lib().goalnet_conv3x3_wgrad_codes(codes.data_ptr(), N, H, W, _s()), "conv3x3_wgrad_codes")
         if len(_WGRAD_CODES) < 64 and N * H * W <= (1 << 22):
             _WGRAD_CODES[ck] = codes
-    ctr = _tile_counters(("conv3x3_wgrad", N, H, W, Cin, Cout), x.device)
+    ctr = _tile_counters(("conv3x3_wgrad", N, H, W, Cin, Cout), x.device) if FUSED_SPLITK else None
     check(lib().goalnet_conv3x3_wgrad(x.data_ptr(), _p(scale), _p(shift), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-                                      codes.data_ptr(), ctr.data_ptr(), N_TILE_CTR, N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
+                                      codes.data_ptr(), _p(ctr), N_TILE_CTR if ctr is not None else 0, N, H, W, Cin, Cout, _s()), "conv3x3_wgrad")
     return dw
 
 
@@ -498,6 +528,16 @@ def conv1d_bwd(x, dz, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
                                    stride, pad, _p(ws), nbytes, _s()), "conv1d_bwd")
 
 
+def conv1d_bwd_small(x, dz, y, w, dx, dw, db, N, Cin, L, Cout, stride=2, pad=1):
+    """conv1d_bwd for N < 64 frames in one launch; y (the layer's ReLU output) gates dz when given"""
+    _chk(x, dz, y, w, dx, dw, db)
+    Lo = (L + 2 * pad - 3) // stride + 1
+    _req(x.numel() == N * Cin * L and dz.numel() == N * Cout * Lo and (y is None or y.numel() == dz.numel()), "conv1d_bwd_small: x / dz / y shapes")
+    _req(dw.numel() == Cout * Cin * 3 and db.numel() == Cout and (dx is None or dx.numel() == x.numel()), "conv1d_bwd_small: dw / db / dx shapes")
+    check(lib().goalnet_conv1d_bwd_small(x.data_ptr(), dz.data_ptr(), _p(y), w.data_ptr(), _p(dx), dw.data_ptr(), db.data_ptr(),
+                                         N, Cin, L, Cout, stride, pad, _s()), "conv1d_bwd_small")
+
+
 def relu_bwd(dy, y, dz):
     _chk(dy, y, dz)
     _req(dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel(), "relu_bwd: argument check failed: dy.is_contiguous() and y.is_contiguous() and dz.is_contiguous() and dy.numel() == y.numel() == dz.numel()")
@@ -512,11 +552,13 @@ def _ptrs(ts):
     return (ctypes.c_void_p * len(ts))(*[_p(t) for t in ts])
 
 
-def mlp_fwd(cat, ws, bs, masks, hs, mults, logit, out):
+def mlp_fwd(cat, ws, bs, masks, hs, mults, logit, out, labels=None, loss=None, dout=None):
     """fusion.0 .. fusion.12 + Sigmoid + 4y+1 on <= 16 rows in one launch. cat (n, K0) may be a view with a row stride;
     ws / bs: 5 weights / biases; masks: 4 dropout multipliers or None; hs: 4 outputs; mults: 4 saved multipliers or None"""
-    _chk(cat, logit, out, *ws, *bs, *masks, *hs, *mults)
+    _chk(cat, logit, out, labels, loss, dout, *ws, *bs, *masks, *hs, *mults)
     n, K0 = cat.shape
+    _req(labels is None or (labels.numel() == n and labels.dtype == F32 and labels.is_contiguous() and loss is not None and dout is not None
+                            and dout.numel() == n), "mlp_fwd: labels (n) need loss (1) and dout (n)")
     _req(len(ws) == 5 and len(bs) == 5 and len(masks) == 4 and len(hs) == 4 and len(mults) == 4, "mlp_fwd: 5 layers, 4 hidden outputs")
     for l, wd in enumerate(MLP_WIDTHS):
         kin = K0 if l == 0 else MLP_WIDTHS[l - 1]
@@ -527,7 +569,7 @@ def mlp_fwd(cat, ws, bs, masks, hs, mults, logit, out):
     ldm = (ctypes.c_int64 * 4)(*[0 if m is None else _ld(m) for m in masks])
     sync = _tile_counters(("mlp_fwd", n, K0), cat.device)
     check(lib().goalnet_mlp_fwd(cat.data_ptr(), _ld(cat), K0, _ptrs(ws), _ptrs(bs), _ptrs(masks), ldm, _ptrs(hs), _ptrs(mults),
-                                logit.data_ptr(), out.data_ptr(), n, sync.data_ptr(), _s()), "mlp_fwd")
+                                logit.data_ptr(), out.data_ptr(), _p(labels), _p(loss), _p(dout), n, sync.data_ptr(), _s()), "mlp_fwd")
 
 
 def mlp_bwd(dout, out, xs, ms, ws, dws, dbs, dcat, db5, voff):
@@ -672,6 +714,15 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_
     _req(g.numel() == n and m.numel() == n and v.numel() == n, "adam_step_dev: argument check failed: g.numel() == n and m.numel() == n and v.numel() == n")
     check(lib().goalnet_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
                                       int(step_bias), grad_scale, _s()), "adam_step_dev")
+
+
+def adam_step_dev_blocks(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_bias=0, max_blocks=128):
+    """adam_step_dev as a background pass on at most max_blocks blocks"""
+    _chk(p, g, m, v)
+    n = p.numel()
+    _req(g.numel() == n and m.numel() == n and v.numel() == n, "adam_step_dev_blocks: p, g, m, v must have the same size")
+    check(lib().goalnet_adam_step_dev_blocks(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2, eps, _ctr(step),
+                                             int(step_bias), grad_scale, int(max_blocks), _s()), "adam_step_dev_blocks")
 
 
 def adam_step_dev_shadow(p, g, m, v, lr, beta1, beta2, eps, step, shadow, shadow_begin, grad_scale=1.0, step_bias=0):

@@ -59,6 +59,9 @@ int goalnet_dropout_mask(float* dst, int64_t n, uint64_t seed, uint32_t tensor_i
 int goalnet_transpose_inner(const float* src, float* dst, int64_t B, int64_t R, int64_t C, void* stream);
 /* dgrad weights: wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci] */
 int goalnet_conv3x3_weight_flip(const float* w_ohwi, float* wt, int Cout, int Cin, void* stream);
+/* two tensors in one launch (conv3's and conv2's weights, flipped in every backward of the 10-frame step) */
+int goalnet_conv3x3_weight_flip2(const float* wa_ohwi, float* wta, int CoutA, int CinA, const float* wb_ohwi, float* wtb, int CoutB, int CinB,
+                                 void* stream);
 
 /* ---- VisBl block 1: conv1 (3->64, k3 s3 p3) + bias + ReLU.  utils.py:151-152, 174-175 ---------- */
 int goalnet_conv1_fwd(const float* x_nchw, const float* w_ohwi, const float* bias, float* y_nhwc,
@@ -111,18 +114,23 @@ int goalnet_bnpool_bwd_bf16p_t(const void* dz, int dz_bf16, const void* p, int p
                                int f16, void* stream);
 /* out[c] = sum over parts of partials[part][c] (row stride `stride` doubles), cast to float */
 int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int C, float* out, void* stream);
-/* Small shapes (the reference's 10-frame sub-batches, main.py:177-196): channel-sliced forms of the passes above. One block
- * owns four channels and walks all pixels, so its per-channel sums are complete inside the block (fp64, fixed order): no
- * partial rows and no finalise launch. fp32 tensors, < 2^24 pixels.
- * forward = goalnet_pool_bnstats_fwd + goalnet_bn_finalize in one launch;
- * backward = goalnet_bn_bwd_reduce + _finalize + goalnet_bnpool_bwd + goalnet_partials_sum (dbias) in one launch. */
+/* Small shapes (the reference's 10-frame sub-batches, main.py:177-196; <= 2^20 elements, C <= 512, fp32): the passes above
+ * with the finalise step folded in. <= 32 blocks of 1024 threads, one partial row each; the last block to arrive sums the rows
+ * of every column (one batch of loads, row order) and writes what goalnet_bn_finalize / goalnet_bn_bwd_finalize /
+ * goalnet_partials_sum would. forward = pool + statistics + finalise in ONE launch; backward = reduce + finalise in one launch
+ * (goalnet_bn_bwd_reduce_small), then either goalnet_bnpool_bwd_small (max-pool / ReLU backward + bias gradient in one launch, a
+ * direct 9-window gather) or the rolling-row goalnet_bnpool_bwd + goalnet_partials_sum (faster at 40 x 40: DESIGN.md §4.3).
+ * ws: goalnet_bn_small_ws_bytes(C); ctr: one int32, zero on entry, zero again on exit. */
+size_t goalnet_bn_small_ws_bytes(int C);
 int goalnet_pool_bn_fwd_small(const float* y, float* p, uint8_t* idx, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps,
                               float* mean, float* invstd, float* scale, float* shift,
-                              int N, int Hc, int Wc, int C, void* stream);
-int goalnet_bn_pool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* mean, const float* invstd,
-                              const float* gamma, float* dgamma, float* dbeta, float* dy, float* dbias,
-                              int N, int Hc, int Wc, int C, void* stream);
+                              void* ws, size_t ws_bytes, int* ctr, int N, int Hc, int Wc, int C, void* stream);
+int goalnet_bn_bwd_reduce_small(const float* dz, const float* p, const float* mean, const float* invstd, const float* gamma,
+                                float* dgamma, float* dbeta, float* coef3, void* ws, size_t ws_bytes, int* ctr,
+                                int N, int Hc, int Wc, int C, void* stream);
+int goalnet_bnpool_bwd_small(const float* dz, const float* p, const uint8_t* idx, const float* coef3, float* dy, float* dbias,
+                             void* ws, size_t ws_bytes, int* ctr, int N, int Hc, int Wc, int C, void* stream);
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
  * (ddp.SyncStats; SURVEY.md §8(e) "SyncBN": all-reduce of per-channel sum(x), sum(x^2)) */
 int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream);
@@ -238,6 +246,10 @@ int goalnet_conv1d_fwd(const float* x, const float* w, const float* b, int relu,
 size_t goalnet_conv1d_bwd_ws_bytes(int N, int Cin, int Cout);
 int goalnet_conv1d_bwd(const float* x, const float* dz, const float* w, float* dx, float* dw, float* db,
                        int N, int Cin, int L, int Cout, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* the same for few frames (N < 64: the reference's sub-batches) in ONE launch, with the layer's own ReLU backward folded in:
+ * y (nullable) = the layer's ReLU output, the effective output gradient is dz * (y > 0); dx nullable; Cin <= 256 */
+int goalnet_conv1d_bwd_small(const float* x, const float* dz, const float* y, const float* w, float* dx, float* dw, float* db,
+                             int N, int Cin, int L, int Cout, int stride, int pad, void* stream);
 /* dz = dy * (y > 0) */
 int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream);
 
@@ -246,6 +258,7 @@ int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void
  * Pointer arrays are HOST arrays of device pointers, read at call time: w / b / dw / db [5] = fusion.0, .3, .6, .9, .12;
  * mask / h / mult [4] = the dropout multipliers (nullable), outputs (n, 512 | 512 | 256 | 128, contiguous) and saved
  * (pre-activation > 0) * mask (nullable) of fusion.0, .3, .6, .9. cat (n, K0) has row stride ldcat; K0 = 640 (audio) or 512.
+ * labels (nullable): the same launch then also evaluates goalnet_mse_bcast(out, labels) -> loss[0], dout[n] (same code, same bits).
  * sync: int32[3] in device memory, zero on entry, zero again on exit ([2] is set, and stays set, if the barrier timed out).
  * Backward: x [5] = cat, h1..h4; m [5] = the saved multipliers of those (mcat with row stride ldmcat, then mult[0..3]);
  * writes dw / db of the five layers, dcat (n, K0) = the gradient wrt the pre-activations behind `cat`, and (db5 nullable)
@@ -253,7 +266,7 @@ int goalnet_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void
 int goalnet_mlp_blocks(void);
 int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const* w, const float* const* b,
                     const float* const* mask, const int64_t* ldmask, float* const* h, float* const* mult,
-                    float* logit, float* out, int n, int* sync, void* stream);
+                    float* logit, float* out, const float* labels, float* loss, float* dout, int n, int* sync, void* stream);
 size_t goalnet_mlp_bwd_ws_bytes(int n);
 int goalnet_mlp_bwd(const float* dout, const float* out, const float* const* x, int64_t ldcat, const float* const* m, int64_t ldmcat,
                     const float* const* w, float* const* dw, float* const* db, float* dcat, int64_t lddcat, float* db5, int voff,
@@ -327,6 +340,10 @@ int goalnet_dropout_masks_dev(float* dst, int n, const int* widths, int layers, 
 /* goalnet_adam_step with the 1-based step count = *step + step_bias (bias 1: the counter holds the completed steps) */
 int goalnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                           double beta2, double eps, const int64_t* step, int64_t step_bias, float grad_scale, void* stream);
+/* the same on at most max_blocks blocks of 256 threads: a background pass that leaves CUs and HBM bandwidth to the kernels it
+ * runs beside (the 10-frame step updates linear5.weight on its own stream under the rest of backward) */
+int goalnet_adam_step_dev_blocks(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                                 double eps, const int64_t* step, int64_t step_bias, float grad_scale, int max_blocks, void* stream);
 /* the same, additionally writing bf16(p_new) for the slice [shadow_begin, shadow_begin + shadow_count) of the arena (both
  * multiples of 4): the next step's bf16 GEMM operand (visbl.linear5.weight) without a separate 7.7 GB cast pass */
 int goalnet_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
