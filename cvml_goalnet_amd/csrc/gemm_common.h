@@ -2,6 +2,8 @@
 // the accumulator -> memory epilogue for the 32x32 MFMA C/D layout (identical for every dtype on gfx950), the
 // XCD-aware tile order and the split-K slab reduction.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace goalnet {
@@ -182,8 +184,10 @@ int pick_splits(int64_t tiles, int ktiles);
 // with output tiles alone: split K into slabs (>= 4 K-tiles each, ~512 blocks), reduced in a fixed order.
 inline int conv_fwd_splits(int64_t tiles, int ktiles) {
     if (tiles >= 256 || ktiles < 8) return 1;
-    int64_t s = (512 + tiles - 1) / tiles;
-    const int64_t smax = ktiles / 4;
+    static const int target = getenv("GOALNET_SPLIT_TARGET") ? atoi(getenv("GOALNET_SPLIT_TARGET")) : 512;      // blocks to aim for (A/B runs)
+    static const int minkt = getenv("GOALNET_SPLIT_MINKT") ? atoi(getenv("GOALNET_SPLIT_MINKT")) : 4;          // K-tiles per split, at least
+    int64_t s = (target + tiles - 1) / tiles;
+    const int64_t smax = ktiles / minkt;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     const int kps = (int)((ktiles + s - 1) / s);

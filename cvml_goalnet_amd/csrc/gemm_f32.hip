@@ -821,7 +821,8 @@ const char* goalnet_conv3x3_fwd_kernel_name(int N, int H, int W, int Cin, int Co
 static int wgrad_splits(int64_t M, int Cin, int Cout) {
     const int64_t tiles = (int64_t)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
     const int ktiles = (int)((M + BK - 1) / BK);
-    int64_t s = (2048 + tiles - 1) / tiles;
+    static const int wtarget = getenv("GOALNET_WGRAD_SPLIT_TARGET") ? atoi(getenv("GOALNET_WGRAD_SPLIT_TARGET")) : 2048;      // A/B runs
+    int64_t s = (wtarget + tiles - 1) / tiles;
     const int64_t smax = ktiles / 4 > 1 ? ktiles / 4 : 1;      // >= 4 K-tiles per split (small sub-batches: few pixels)
     if (s > smax) s = smax;
     if (s > 512) s = 512;

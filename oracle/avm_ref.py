@@ -132,7 +132,9 @@ def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visua
     `inter`: optional dict that receives named intermediate activations.
     `pool_taps`: optional {1,2,3 -> uint8 (N,C,Hp,Wp)} argmax positions to force in the three max-pools
     (tests only, see _ForcedMaxPool); None = the reference's own behaviour. `relu_gates`: optional {1,2,3 -> bool (N,C,Hp,Wp)}, with
-    pool_taps: whether the ReLU passes at each forced argmax position (tests only, see _vis_block).
+    pool_taps: whether the ReLU passes at each forced argmax position (tests only, see _vis_block); optional keys "visbl.linear5",
+    "fusion.0" / ".3" / ".6" / ".9" -> bool (N, width): the gate of that layer's ReLU (tests of the 16-bit modes, whose 4e-3
+    activation noise flips ~0.5 % of a ReLU network's gates: the gradient's relative error is then ~sqrt(0.5 %), whatever the kernels do).
     """
     pt = pool_taps or {}
     rg = relu_gates or {}
@@ -145,8 +147,13 @@ def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visua
     x = _vis_block(visual, p, b, 1, 3, 3, inter, pt.get(1), rg.get(1))
     x = _vis_block(x, p, b, 2, 1, 1, inter, pt.get(2), rg.get(2))
     x = _vis_block(x, p, b, 3, 1, 1, inter, pt.get(3), rg.get(3))
+    def relu_g(z, key):
+        """ReLU, or (tests) the given gate at this layer: z * gate — see _vis_block on why gates are forced"""
+        g = rg.get(key)
+        return F.relu(z) if g is None else z * g.to(z.dtype)
+
     x = torch.flatten(x, 1)                                   # NCHW flatten: c*H*W + h*W + w
-    x = F.relu(F.linear(x, p["visbl.linear5.weight"], p["visbl.linear5.bias"]))
+    x = relu_g(F.linear(x, p["visbl.linear5.weight"], p["visbl.linear5.bias"]), "visbl.linear5")
     v = drop(x, dm[0])
     if inter is not None:
         inter["visbl.drop5"] = v
@@ -165,7 +172,7 @@ def forward(p: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor], audio, visua
 
     # fusion, utils.py:242-258
     for li, k in enumerate((0, 3, 6, 9)):
-        x = F.relu(F.linear(x, p[f"fusion.{k}.weight"], p[f"fusion.{k}.bias"]))
+        x = relu_g(F.linear(x, p[f"fusion.{k}.weight"], p[f"fusion.{k}.bias"]), f"fusion.{k}")
         x = drop(x, dm[1 + li])
         if inter is not None:
             inter[f"fusion.{k + 2}"] = x

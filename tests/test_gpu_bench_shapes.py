@@ -23,7 +23,8 @@ Tolerances. fp32: predictions / logits 2e-5 abs, loss 2e-5 rel; every gradient t
 1 024 frames sums 64 x more terms than the 16-frame oracle step, so a fixed relative bound against the fp32 oracle would
 measure the oracle's rounding, not the kernels' (measured: the convolution weight gradients of the 1 024-frame step are 5 x
 CLOSER to the fp64 truth than the oracle's own fp32 arithmetic); updated parameters inside their Adam-sensitivity bound.
-bf16: pre-sigmoid logit max-abs <= 1e-3 vs the fp32 oracle (north star), weight gradients relative L2 <= 0.15.
+bf16: pre-sigmoid logit max-abs <= 1e-3 vs the fp32 oracle (north star), weight gradients relative L2 <= 2.2e-2 (fp16: 3e-3)
+under the device's routing and ReLU gates.
 Dropout: masks from the seed formula (same bits on both sides); BatchNorm: train mode.
 """
 import gc
@@ -42,7 +43,11 @@ DEV = "cuda:0"
 LR = 1e-3
 # 16-bit modes: (logit max-abs vs the fp32 oracle, weight-gradient relative L2, prediction / loss / running-stat tolerance).
 # bf16: the north star's 1e-3 on the logit; fp16 (11 significand bits, measured 2e-5 .. 4e-5) is held to a quarter of it.
-TOL16 = {"bf16": (1e-3, 0.15, 4e-3), "fp16": (2.5e-4, 0.05, 1e-3)}
+# Weight gradients, under the device's max-pool routing AND ReLU gates (see _run_case): measured worst relative L2 over every
+# shape of this file 7.2e-3 (bf16, visbl.linear5.weight; conv3 5.8e-3, conv2 4.8e-3, conv1 4.8e-3, fusion.* <= 2e-3, audbl.* <= 4e-4)
+# and 8.9e-4 (fp16); the bounds are 3 x that. (Round 2 held bf16 to 0.15 and measured 1e-1: with the oracle's OWN gates in the
+# fusion MLP the comparison measured ReLU flips, not arithmetic.)
+TOL16 = {"bf16": (1e-3, 2.2e-2, 4e-3), "fp16": (2.5e-4, 3e-3, 1e-3)}
 
 
 def _fresh_model(h, precision, seed=7):
@@ -68,6 +73,16 @@ def _gates_first(ctx, k):
     """the ReLU gates the device's backward applies at the argmax positions — (p > 0), csrc/pool_bn.hip reads the mask off the
     pooled value — of the first k frames as (k, C, Hp, Wp) bool CPU tensors"""
     return {i: (ctx[f"p{i}"][:k].float() > 0).cpu().permute(0, 3, 1, 2).contiguous() for i in (1, 2, 3)}
+
+
+def _mlp_gates_first(ctx, k, voff):
+    """ReLU gates of linear5 and of the four fusion layers, read off the multipliers the device saved for backward
+    ((pre-activation > 0) * dropout multiplier: where the dropout multiplier is 0 the gate does not matter)"""
+    ms = ctx["ms"]
+    g = {"visbl.linear5": (ms[0][:k, voff:] != 0).cpu()}
+    for key, m in zip(("fusion.0", "fusion.3", "fusion.6", "fusion.9"), ms[1:]):
+        g[key] = (m[:k] != 0).cpu()
+    return g
 
 
 def gate_disagreements(inter, taps, gates):
@@ -113,7 +128,14 @@ def _run_case(precision, h, n_unique, copies, data_seed=synth.BASE_SEED, model_s
         for c in {0, copies // 2, copies - 1}:
             assert torch.equal(raw[c], raw[0]), f"block {i}: copy {c} routed its max-pool differently from copy 0"
     taps = _taps_first(ctx, n_unique)
-    gates = _gates_first(ctx, n_unique) if precision == "fp32" else None
+    # fp32: the conv blocks' gates (a window maximum within rounding of zero). 16-bit modes: ALSO linear5's and the fusion layers'
+    # gates — 16-bit storage perturbs the activations by ~4e-3 of their scale, which flips ~0.5 % of the network's ReLU gates, and a
+    # flipped gate changes its unit's gradient at O(1): the weight-gradient error is then ~sqrt(0.5 %) ~ 7-12 % whatever the kernels
+    # do (round 2's 0.15 bound measured THAT: the pure-fp32 fusion / AudBl layers showed 2-5 % as well). Under the device's gates
+    # the comparison measures the 16-bit arithmetic.
+    gates = _gates_first(ctx, n_unique)
+    if precision != "fp32":
+        gates.update(_mlp_gates_first(ctx, n_unique, ctx["hs"][0].shape[1] - 512))
     logit = model.last_logit[:n_unique].cpu()
     del ctx
     gc.collect()
