@@ -51,6 +51,7 @@ PROTOTYPES = {
     "goalnet_bn_bwd_reduce_small": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_bnpool_bwd_small": (c_int, [P, P, P, P, P, P, P, c_size_t, P, c_int, c_int, c_int, c_int, P]),
     "goalnet_partials_sum": (c_int, [P, c_int, c_int64, c_int, P, P]),
+    "goalnet_partials_sum2": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P]),
     "goalnet_partials_sum_f64": (c_int, [P, c_int, c_int64, c_int, P, P]),
     "goalnet_conv3x3_fwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_int, P]),
@@ -119,6 +120,7 @@ PROTOTYPES = {
     "goalnet_grad_finite_check": (c_int, [P, c_int64, P, c_int64, P, P, P]),
     "goalnet_counters_add4": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P]),
     "goalnet_counters_add4_guarded": (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
+    "goalnet_rows_scatter_tick": (c_int, [ctypes.POINTER(RowCopy), c_int, P, c_int64, c_int64, c_int64, c_int64, P, P]),
     "goalnet_rows_copy_batch": (c_int, [ctypes.POINTER(RowCopy), c_int, P]),
     "goalnet_frames_preprocess": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P]),
     "goalnet_knapsack_ws_bytes": (c_size_t, [c_int, c_int]),

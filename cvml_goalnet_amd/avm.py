@@ -201,6 +201,7 @@ class AVM(nn.Module):
         self.last_used_w5b = False
         self._side_stream = None
         self._adam_stream = None
+        self._dbias_pending = {}
         self._fused_loss, self._fused_loss_done = None, False      # train_step -> forward_device: (labels, loss, dout) for the fused MLP launch
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
@@ -754,10 +755,10 @@ class AVM(nn.Module):
                 return dy
             dparts = torch.empty(ops.stat_parts(8 * n) * c, dtype=torch.float64, device=dev)
             ops.bnpool_bwd(dbn, p, idx, coef3, dy, dparts, n, hc, wc, c)
-            if i == 1:
-                ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias"))
-            else:
-                self._fork.run(lambda: ops.partials_sum(dparts, ops.stat_parts(8 * n), c, c, G(f"visbl.conv{i}.bias")), dparts)
+            # the bias gradients' row sums feed nothing but Adam: conv3's and conv2's go out together at the end of backward (one
+            # launch, side stream); conv1's is written by goalnet_conv1_wgrad from its own sums of dy
+            if i > 1:
+                self._dbias_pending[i] = dparts
             return dy
         coef3 = torch.empty(3 * c, dtype=F32, device=dev)
         partials = torch.empty(ops.stat_parts(npix // 64) * 2 * c, dtype=torch.float64, device=dev)
@@ -805,6 +806,7 @@ class AVM(nn.Module):
         hs, ms = ctx["hs"], ctx["ms"]
         # small steps: weight / bias gradients and the AudBl branch run on a side stream under the dX chain (_Fork)
         fork = self._fork = _Fork(self, self._fork_ok(n) and dout.is_cuda)
+        self._dbias_pending = {}
 
         def bucket_done(k):
             if on_bucket:
@@ -955,6 +957,10 @@ class AVM(nn.Module):
         # block 1 (utils.py:174-177); conv1's input needs no gradient
         dy1 = self._block_bwd(dbn1, ctx, 1, n, h1, w1, 64)
         ops.conv1_wgrad(ctx["visual"], dy1, G("visbl.conv1.weight"), G("visbl.conv1.bias"), n, h, w)
+        if len(self._dbias_pending) == 2:
+            d3, d2 = self._dbias_pending[3], self._dbias_pending[2]
+            fork.run(lambda: ops.partials_sum2(d3, 512, G("visbl.conv3.bias"), d2, 256, G("visbl.conv2.bias")), d3, d2)
+        self._dbias_pending = {}
         fork.join()                                 # every gradient is in the arena before anything downstream (Adam, all-reduce) reads it
         self._fork = _Fork(self, False)
         if on_bucket:
@@ -997,9 +1003,11 @@ class AVM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # device-resident fused train step: forward, broadcast MSE, backward, Adam
     # ------------------------------------------------------------------------------------------
-    def train_step(self, audio, visual, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, _loop_tick=(0, 0)):
+    def train_step(self, audio, visual, labels, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, _loop_tick=(0, 0), _scatter=None):
         """main.py:187-193 on GPU tensors. Returns (loss (1,), pred (N,)) as GPU tensors, no host sync.
-        `_loop_tick`: (frames, sub-batches) the caller's loop counters advance by (loop.VideoTrainer)."""
+        `_loop_tick`: (frames, sub-batches) the caller's loop counters advance by (loop.VideoTrainer); `_scatter(loss, pred)` -> row-copy
+        segments (ops.rows_copy_batch form, cursors as they stand BEFORE the tick) that the step's last launch writes before it advances
+        the counters (the per-video predictions / losses arrays of loop.VideoTrainer)."""
         self._defer_tick, self._pending_drop_tick = True, 0
         n0 = visual.shape[0]
         loss = torch.empty(1, dtype=F32, device=self._device)
@@ -1078,7 +1086,9 @@ class AVM(nn.Module):
         self.adam_step(lr, betas, eps, scale / lscale, _tick=False, _guard=guard, _done=done_early)
         if early_bg and done_early:
             torch.cuda.current_stream().wait_stream(self._adam_stream)     # the background pass joins before the step count moves
-        if guard is not None:
+        if _scatter is not None:
+            ops.rows_scatter_tick(_scatter(loss, out), self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1], bad_step=guard)
+        elif guard is not None:
             # a step whose Adam was skipped is not counted (torch's GradScaler does not count it either): the retry runs under
             # the same step count; `_adam_t` on the host counts ATTEMPTED steps
             ops.counters_add4_guarded(self._state, 1, self._pending_drop_tick, _loop_tick[0], _loop_tick[1], guard)

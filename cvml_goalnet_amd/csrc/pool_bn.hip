@@ -944,6 +944,19 @@ __global__ __launch_bounds__(256) void partials_sum_kernel(const double* __restr
     if (c < C && threadIdx.x < 16) out[c] = (float)s;
 }
 
+// two partial-sum arrays in one launch (the conv3 / conv2 bias gradients of the 10-frame step): blocks [0, blocks_a) serve the first
+__global__ __launch_bounds__(256) void partials_sum2_kernel(const double* __restrict__ pa, int na, int Ca, float* __restrict__ oa, int blocks_a,
+                                                           const double* __restrict__ pb, int nb, int Cb, float* __restrict__ ob) {
+    __shared__ double sm[256];
+    const bool first = (int)blockIdx.x < blocks_a;
+    const double* partials = first ? pa : pb;
+    const int nparts = first ? na : nb, C = first ? Ca : Cb;
+    float* out = first ? oa : ob;
+    const int c = (first ? blockIdx.x : blockIdx.x - blocks_a) * 16 + (threadIdx.x & 15);
+    const double s = column_sum16(partials + c, nparts, C, c < C, sm);
+    if (c < C && threadIdx.x < 16) out[c] = (float)s;
+}
+
 __global__ __launch_bounds__(256) void partials_sum_f64_kernel(const double* __restrict__ partials, int nparts, int64_t stride,
                                                               int C, double* __restrict__ out) {
     __shared__ double sm[256];
@@ -1256,6 +1269,15 @@ int goalnet_partials_sum(const double* partials, int nparts, int64_t stride, int
     GN_REQUIRE(nparts > 0 && C > 0 && stride >= C, GOALNET_E_SHAPE, "partials_sum: bad dims");
     hipLaunchKernelGGL(partials_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, nparts, stride, C, out);
     GN_LAUNCH_CHECK("partials_sum");
+    return 0;
+}
+
+int goalnet_partials_sum2(const double* pa, int na, int Ca, float* oa, const double* pb, int nb, int Cb, float* ob, void* stream) {
+    GN_REQUIRE(pa && oa && pb && ob, GOALNET_E_NULL, "partials_sum2: null pointer");
+    GN_REQUIRE(na > 0 && Ca > 0 && nb > 0 && Cb > 0, GOALNET_E_SHAPE, "partials_sum2: bad dims");
+    const int ba = (Ca + 15) / 16, bb = (Cb + 15) / 16;
+    hipLaunchKernelGGL(partials_sum2_kernel, dim3(ba + bb), dim3(256), 0, (hipStream_t)stream, pa, na, Ca, oa, ba, pb, nb, Cb, ob);
+    GN_LAUNCH_CHECK("partials_sum2");
     return 0;
 }
 

@@ -43,6 +43,27 @@ __global__ __launch_bounds__(256) void rows_copy_batch_kernel(RowCopies rc) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// the step's last launch: scatter the results (<= 4 small segments, ONE block) and then advance the four counters. One block reads
+// every cursor before it moves any: predictions.extend(...), losses.append(...), subbatch_offset += n (main.py:195-198) in one launch.
+__global__ __launch_bounds__(256) void rows_scatter_tick_kernel(RowCopies rc, int count, int64_t* ctr, int64_t d0, int64_t d1, int64_t d2,
+                                                               int64_t d3, int64_t* bad_step) {
+    for (int k = 0; k < count; ++k) {
+        const goalnet_rowcopy sg = rc.seg[k];
+        const int64_t row_words = sg.row_bytes / 4, words = row_words * sg.nrows, base = (*sg.cursor + sg.cursor_bias) * row_words;
+        const uint32_t* s = (const uint32_t*)sg.src + (sg.gather ? base : 0);
+        uint32_t* d = (uint32_t*)sg.dst + (sg.gather ? 0 : base);
+        for (int64_t i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i == 0) {
+        if (bad_step && *bad_step == ctr[0] + d0) *bad_step = 0;       // precision = "fp16": a skipped step is not counted (counters_add4_guarded)
+        else ctr[0] += d0;
+    } else if (i < 4) {
+        ctr[i] += i == 1 ? d1 : i == 2 ? d2 : d3;
+    }
+}
+
 struct Widths { int w[8]; int64_t off[9]; };
 
 __global__ __launch_bounds__(256) void dropout_masks_dev_kernel(float* dst, int n, Widths ws, int layers, uint64_t seed,
@@ -117,6 +138,23 @@ int goalnet_rows_copy_batch(const goalnet_rowcopy* segs, int count, void* stream
     }
     hipLaunchKernelGGL(rows_copy_batch_kernel, dim3(grid1(most, 2048), (unsigned)count), dim3(256), 0, (hipStream_t)stream, rc);
     GN_LAUNCH_CHECK("rows_copy_batch");
+    return 0;
+}
+
+int goalnet_rows_scatter_tick(const goalnet_rowcopy* segs, int count, int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
+                              int64_t* bad_step, void* stream) {
+    GN_REQUIRE(segs && counters, GOALNET_E_NULL, "rows_scatter_tick: null pointer");
+    GN_REQUIRE(count >= 1 && count <= GOALNET_ROWCOPY_MAX, GOALNET_E_SHAPE, "rows_scatter_tick: 1..%d segments", GOALNET_ROWCOPY_MAX);
+    RowCopies rc;
+    for (int i = 0; i < count; ++i) {
+        const goalnet_rowcopy& g = segs[i];
+        GN_REQUIRE(g.src && g.dst && g.cursor, GOALNET_E_NULL, "rows_scatter_tick: null pointer in segment %d", i);
+        GN_REQUIRE(g.row_bytes > 0 && (g.row_bytes & 3) == 0 && g.nrows > 0 && g.row_bytes / 4 * g.nrows <= (1 << 20), GOALNET_E_SHAPE,
+                   "rows_scatter_tick: segment %d: rows must be a positive multiple of 4 bytes, <= 4 MB in all (one block copies them)", i);
+        rc.seg[i] = g;
+    }
+    hipLaunchKernelGGL(rows_scatter_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rc, count, counters, d0, d1, d2, d3, bad_step);
+    GN_LAUNCH_CHECK("rows_scatter_tick");
     return 0;
 }
 

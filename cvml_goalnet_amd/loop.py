@@ -85,11 +85,16 @@ class VideoTrainer:
             segs.append((self._aud, aud, n, st[2], 0, True))
         ops.rows_copy_batch(segs)                                       # frames[a:b], labels[a:b], audios[a:b]
         # train_step advances all four counters in its last launch: cursor += n, sub-batch index += 1
-        loss, pred = m.train_step(aud, vis, lab, self.lr, self.betas, self.eps, _loop_tick=(n, 1))
         if m.head == "classifier":
+            loss, pred = m.train_step(aud, vis, lab, self.lr, self.betas, self.eps, _loop_tick=(n, 1))
             pred = ops.argmax_plus1(pred, torch.empty(n, dtype=F32, device=dev))        # main.py:190: argmax + 1 is what gets collected
-        # predictions.extend(...), losses.append(...) at the positions the step started from
-        ops.rows_copy_batch([(self._pred, pred, n, st[2], -n, False), (self._loss, loss, 1, st[3], -1, False)])
+            # predictions.extend(...), losses.append(...) at the positions the step started from
+            ops.rows_copy_batch([(self._pred, pred, n, st[2], -n, False), (self._loss, loss, 1, st[3], -1, False)])
+            return
+        # regression head: that same last launch first writes predictions.extend(...), losses.append(...) at the positions the step
+        # started from (main.py:195-196), then moves the counters
+        m.train_step(aud, vis, lab, self.lr, self.betas, self.eps, _loop_tick=(n, 1),
+                     _scatter=lambda loss, pred: [(self._pred, pred, n, st[2], 0, False), (self._loss, loss, 1, st[3], 0, False)])
 
     def _host_bookkeeping_after_replay(self):
         """What an eager train_step does on the host besides launching kernels."""

@@ -246,6 +246,14 @@ def partials_sum(partials, nparts, stride, C, out):
     check(lib().goalnet_partials_sum(partials.data_ptr(), nparts, stride, C, out.data_ptr(), _s()), "partials_sum")
 
 
+def partials_sum2(pa, Ca, oa, pb, Cb, ob):
+    """partials_sum of two [rows][C] arrays in one launch"""
+    _chk(pa, oa, pb, ob)
+    _req(oa.numel() == Ca and ob.numel() == Cb, "partials_sum2: out sizes")
+    check(lib().goalnet_partials_sum2(pa.data_ptr(), _rows(pa, Ca), Ca, oa.data_ptr(), pb.data_ptr(), _rows(pb, Cb), Cb, ob.data_ptr(), _s()),
+          "partials_sum2")
+
+
 def partials_sum_f64(partials, C, out):
     """out[c] (double) = sum over the rows of partials[rows][C]"""
     _chk(partials, out)
@@ -770,6 +778,21 @@ def rows_copy_batch(segments):
         src, dst = (table, block) if gather else (block, table)
         arr[k] = _lib.RowCopy(src.data_ptr(), dst.data_ptr(), row_bytes, nrows, 1 if gather else 0, _ctr(cursor), int(bias))
     check(lib().goalnet_rows_copy_batch(arr, len(segments), _s()), "rows_copy_batch")
+
+
+def rows_scatter_tick(segments, counters, d0, d1, d2, d3, bad_step=None):
+    """rows_copy_batch(segments) followed by counters_add4[_guarded] in ONE launch (the segments are small)"""
+    arr = (_lib.RowCopy * len(segments))()
+    for k, (table, block, nrows, cursor, bias, gather) in enumerate(segments):
+        _chk(table, block)
+        _req(table.is_contiguous() and block.is_contiguous() and table.dtype == block.dtype, "rows_scatter_tick: contiguous tensors of one dtype")
+        row_bytes = table[0].numel() * table.element_size() if table.dim() > 1 else table.element_size()
+        _req(block.numel() * block.element_size() == row_bytes * nrows, "rows_scatter_tick: block size")
+        src, dst = (table, block) if gather else (block, table)
+        arr[k] = _lib.RowCopy(src.data_ptr(), dst.data_ptr(), row_bytes, nrows, 1 if gather else 0, _ctr(cursor), int(bias))
+    _req(counters.is_cuda and counters.dtype == I64 and counters.numel() == 4 and counters.is_contiguous(), "rows_scatter_tick: int64[4] counters")
+    check(lib().goalnet_rows_scatter_tick(arr, len(segments), counters.data_ptr(), int(d0), int(d1), int(d2), int(d3),
+                                          0 if bad_step is None else _ctr(bad_step), _s()), "rows_scatter_tick")
 
 
 def rows_gather(table, block, nrows, cursor):

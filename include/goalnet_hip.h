@@ -134,6 +134,8 @@ int goalnet_bnpool_bwd_small(const float* dz, const float* p, const uint8_t* idx
 /* same in double: the one-row form of a partials array that a rank contributes to the cross-rank BatchNorm sums
  * (ddp.SyncStats; SURVEY.md §8(e) "SyncBN": all-reduce of per-channel sum(x), sum(x^2)) */
 int goalnet_partials_sum_f64(const double* partials, int nparts, int64_t stride, int C, double* out, void* stream);
+/* goalnet_partials_sum of two arrays in one launch */
+int goalnet_partials_sum2(const double* pa, int na, int Ca, float* oa, const double* pb, int nb, int Cb, float* ob, void* stream);
 
 /* ---- VisBl blocks 2,3: conv 3x3 s1 p1 as implicit GEMM on fp32 MFMA.  utils.py:156-157, 161-162 --- */
 /* y = [relu](conv(bnapply(x), w) + bias).  scale/shift (per input channel) may be NULL (no BN on load);
@@ -406,6 +408,10 @@ typedef struct {
     const void* src; void* dst; int64_t row_bytes; int nrows; int gather; const int64_t* cursor; int64_t cursor_bias;
 } goalnet_rowcopy;
 int goalnet_rows_copy_batch(const goalnet_rowcopy* segs, int count, void* stream);
+/* the last launch of a sub-batch step: goalnet_rows_copy_batch (scatter / gather segments, small: one block copies them) and THEN
+ * goalnet_counters_add4[_guarded] (bad_step nullable) — the cursors are read before any counter moves. main.py:195-198 */
+int goalnet_rows_scatter_tick(const goalnet_rowcopy* segs, int count, int64_t* counters, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
+                              int64_t* bad_step, void* stream);
 
 #ifdef __cplusplus
 }
