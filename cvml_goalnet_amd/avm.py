@@ -744,8 +744,8 @@ class AVM(nn.Module):
         small = self._small_bn(dbn, p, n, hc, wc, c) and not (self._half and i > 1)
         if small:
             # the reference's operating point: reduce + finalise in one launch (csrc/pool_bn.hip "small shapes"), then the rolling-row
-            # max-pool / ReLU backward (measured faster at this size than the one-launch 9-window gather: 14 against 35 us) with its
-            # bias-gradient row sum on the side stream
+            # max-pool / ReLU backward (13 us; the one-launch 9-window gather from global memory 35), its bias-gradient rows summed at
+            # the end of backward on the side stream
             coef3 = torch.empty(3 * c, dtype=F32, device=dev)
             ops.bn_bwd_reduce_small(dbn, p, st[0], st[1], self._pflat(f"visbl.bnorm{i}.weight"), G(f"visbl.bnorm{i}.weight"),
                                     G(f"visbl.bnorm{i}.bias"), coef3, n, hc, wc, c)

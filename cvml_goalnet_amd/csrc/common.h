@@ -59,6 +59,45 @@ __device__ __forceinline__ void dev_stores_done_block() {
 // after the block has seen the other blocks' ticket / arrival: loads below this point stay below it
 __device__ __forceinline__ void dev_loads_after() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
+// ---- bounded grid barrier on top of that hand-over: for launches whose blocks are all co-resident (grid <= one block per CU) --------
+// sync: int32[3] in device memory, zero on entry: [0] arrivals, [1] departures, [2] error flag. grid_wait returns false when the
+// other blocks did not arrive within ~1 s (the caller leaves at once; [2] stays set): no wave spins forever. grid_leave, called once
+// by every block after its last wait, restores [0] and [1] to zero for the next launch.
+constexpr int GN_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ void grid_arrive(int* sync) {
+    dev_stores_done_block();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool grid_wait(int* sync, int phase, int nblocks) {
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        const int target = phase * nblocks;
+        int spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < GN_SPIN_LIMIT) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+        }
+        s_ok = spins < GN_SPIN_LIMIT;
+        if (!s_ok) __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    dev_loads_after();
+    return s_ok != 0;
+}
+__device__ __forceinline__ bool grid_barrier(int* sync, int phase, int nblocks) {
+    grid_arrive(sync);
+    return grid_wait(sync, phase, nblocks);
+}
+__device__ __forceinline__ void grid_leave(int* sync, int nblocks) {
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nblocks - 1) {
+            __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -140,7 +140,10 @@ struct MCLoader {
     };
     static constexpr bool KC = false;
     static constexpr bool ONE_STAGE = true;
-    static constexpr int ONE_STAGE_BLOCKS = 4;    // blocks per CU with one LDS stage (register budget 128; 3: budget 168)
+#ifndef GN_MC_BLOCKS
+#define GN_MC_BLOCKS 4
+#endif
+    static constexpr int ONE_STAGE_BLOCKS = GN_MC_BLOCKS;    // blocks per CU with one LDS stage (register budget 128; 3: budget 168)
     const float* x;
     int64_t ld;
     int kred, k0;

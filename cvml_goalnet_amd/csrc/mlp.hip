@@ -20,7 +20,6 @@ namespace {
 
 constexpr int MLP_BLOCKS = 64;
 constexpr int KMAX = 640;                 // widest layer input (fusion.0 with audio: 128 + 512)
-constexpr int SPIN_LIMIT = 1 << 22;       // x s_sleep(2) + an atomic load: about a second
 
 struct MlpFwdP {
     const float* x0; int64_t ldx0; int K0;          // cat (n, K0), row stride ldx0
@@ -49,43 +48,7 @@ struct MlpBwdP {
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// phase = 1, 2, ...: returns false when the other blocks did not arrive in time (the caller leaves at once). What the blocks
-// hand to each other across the barrier is written with st_dev and read with ld_dev (common.h: no L2 flush).
-__device__ __forceinline__ void grid_arrive(int* sync) {
-    dev_stores_done_block();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool grid_wait(int* sync, int phase, int nblocks) {
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        const int target = phase * nblocks;
-        int spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spins < SPIN_LIMIT) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
-        }
-        s_ok = spins < SPIN_LIMIT;
-        if (!s_ok) __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    dev_loads_after();
-    return s_ok != 0;
-}
-__device__ __forceinline__ bool grid_barrier(int* sync, int phase, int nblocks) {
-    grid_arrive(sync);
-    return grid_wait(sync, phase, nblocks);
-}
-
-// after the last phase: the last block to leave restores the counters for the next launch
-__device__ __forceinline__ void grid_leave(int* sync, int nblocks) {
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(&sync[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == nblocks - 1) {
-            __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
+// grid_arrive / grid_wait / grid_barrier / grid_leave: common.h (bounded grid barrier over sc1 hand-overs)
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward

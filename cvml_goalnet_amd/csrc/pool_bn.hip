@@ -468,6 +468,12 @@ __global__ __launch_bounds__(SMALL_T) void bnpool_bwd_small_kernel(const float* 
     for (int c = tid; c < C; c += SMALL_T) dbias[c] = (float)dsm[c];
 }
 
+// (Round 3 also built, measured and dropped three other decompositions of these passes: one block per channel slice over ALL pixels
+// with no cross-block step — 68 / 59 us for the forward / reduce against 24 / 20 here, a handful of CUs cannot keep enough loads in
+// flight; a max-pool / ReLU backward per (slice, frame) out of LDS — 9 us for block 3 against 13 for the rolling-row kernel, slower for
+// blocks 1 and 2, no gain on the step; and the whole backward of a block as one launch around a grid barrier — 75 us against 23 + 9,
+// 160 workgroups of 1024 threads polling one arrival counter. DESIGN.md §4.3.)
+
 // ------------------------------------------------------------------------------------------------
 // v2 kernels: one block = (frame slot, 32-channel slice). The three image rows a 3x3 / stride-1 window needs are
 // kept in a rolling LDS buffer, so every HBM byte is read exactly once (the v1 kernels above re-read each element

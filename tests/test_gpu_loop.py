@@ -243,3 +243,44 @@ def test_eval_video_matches_the_oracle_forward_and_broadcast_loss():
     sd = model.state_dict()
     for k, v in b.items():                                               # running statistics were updated, as in the reference
         assert torch.allclose(sd[k].double(), v.double(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("n,audio", [(10, True), (16, True), (3, False)])
+def test_small_step_one_launch_kernels_match_the_multi_launch_forms(n, audio, monkeypatch):
+    """Round 3, the reference's operating point (<= 16 frames of 40 x 40): the fusion MLP forward / backward as one launch each
+    (csrc/mlp.hip, grid barriers over sc1 hand-offs), the pool / BatchNorm passes with their finalise step folded in
+    (csrc/pool_bn.hip "small shapes"), the one-launch Conv1d backward, the batched weight flips and bias-gradient sums, and the
+    scatter + counter tick in the step's last launch. The same two steps with every one of them switched off
+    (GOALNET_MLP_FUSED=0, GOALNET_SMALL_BN=0: the multi-launch kernels of rounds 1-2) must give the same predictions, losses,
+    gradients and parameters up to fp32 summation order; no grid barrier may have timed out."""
+    h = 40
+    vis = torch.from_numpy(synth.make_visual(n, h, h)).to(DEV)
+    aud = torch.from_numpy(synth.make_audio(n)).to(DEV) if audio else None
+    lab = torch.from_numpy(synth.make_labels(n)).to(DEV)
+
+    def two_steps():
+        m = load_model(h, audio)
+        out = []
+        for _ in range(2):
+            loss, pred = m.train_step(aud, vis, lab)
+            out.append((loss.clone(), pred.clone(), m._garena.clone()))
+        torch.cuda.synchronize()
+        return m, out
+
+    fused_m, fused = two_steps()
+    assert not ops.mlp_sync_error(torch.device(DEV), n, 640 if audio else 512), "a grid barrier of the fused MLP kernels timed out"
+    monkeypatch.setenv("GOALNET_MLP_FUSED", "0")
+    monkeypatch.setenv("GOALNET_SMALL_BN", "0")
+    plain_m, plain = two_steps()
+    for s, ((lf, pf, gf), (lp, pp, gp)) in enumerate(zip(fused, plain)):
+        assert (pf - pp).abs().max().item() <= 2e-6, f"step {s}: predictions"
+        assert abs(lf.item() - lp.item()) <= 2e-6 * max(1.0, abs(lp.item())), f"step {s}: loss"
+        for sp in fused_m._specs:
+            a, b = gf[sp.offset:sp.offset + sp.numel], gp[sp.offset:sp.offset + sp.numel]
+            scale = max(b.abs().max().item(), 1e-30)
+            tol = 2e-5 if (sp.name.endswith(".bias") or ".bnorm" in sp.name) else 5e-6      # cancelling sums (test_gpu_avm._is_reduction_grad)
+            assert (a - b).abs().max().item() <= tol * scale + 1e-9, f"step {s}: gradient of {sp.name}"
+    # after two Adam steps: inside the first-order sensitivity bound of the gradient differences (near-zero gradients turn into +-lr kicks)
+    d = (fused_m._arena - plain_m._arena).abs().max().item()
+    assert d <= 2 * 2 * LR, f"parameters differ by {d}"
+    assert torch.equal(fused_m._state[:2], plain_m._state[:2])
