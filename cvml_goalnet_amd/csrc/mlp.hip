@@ -11,6 +11,8 @@
 // always co-resident on 256 CUs, also beside other kernels of the step (side-stream work, graph branches).
 //
 // All sums run in a fixed order (deterministic); fp32 throughout, as the reference.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mse.h"
 
@@ -18,7 +20,8 @@ using namespace goalnet;
 
 namespace {
 
-constexpr int MLP_BLOCKS = 64;
+constexpr int MLP_BLOCKS = 64;            // backward
+constexpr int MLP_FWD_BLOCKS = 64;        // forward (16 | 32 | 64 instantiated; measured 813 | 785 | 771 us per 10-frame step)
 constexpr int KMAX = 640;                 // widest layer input (fusion.0 with audio: 128 + 512)
 
 struct MlpFwdP {
@@ -53,18 +56,20 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-// Per wave: layers 0 and 1 give it two columns, layer 2 one, layer 3 one for the first half of the waves. All of a wave's
-// weights (13 float4 per lane) are requested at kernel start — they depend on nothing — so that between two barriers only the
-// previous layer's activations have to arrive.
-template <int MR>
+// NB blocks = 4 NB waves; wave gw takes columns gw, gw + 4 NB, ... of every layer (512 | 512 | 256 | 128 columns: with NB = 32 that is
+// 4 | 4 | 2 | 1 per wave). All of a wave's weights (25 float4 per lane at NB = 32) are requested at kernel start — they depend on
+// nothing — so that between two barriers only the previous layer's activations have to arrive.
+template <int MR, int NB>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
     __shared__ __attribute__((aligned(16))) float xs[MR * KMAX];
+    constexpr int NW = NB * 4;
+    constexpr int C0 = 512 / NW > 0 ? 512 / NW : 1, C2 = 256 / NW > 0 ? 256 / NW : 1, C3 = 128 / NW > 0 ? 128 / NW : 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int gw = blockIdx.x * 4 + wv, NW = gridDim.x * 4;          // 256 waves
+    const int gw = blockIdx.x * 4 + wv;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 w0[2][3], w1[2][2], w2[2], w3;
+    float4 w0[C0][3], w1[C0][2], w2[C2][2], w3[C3];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < C0; ++c) {
         const int j = gw + c * NW;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -78,15 +83,52 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k = lane * 4 + 256 * i;
-        w2[i] = (gw < P.J[2] && k < P.J[1]) ? *reinterpret_cast<const float4*>(P.w[2] + (int64_t)gw * P.J[1] + k) : z4;
+    for (int c = 0; c < C2; ++c) {
+        const int j = gw + c * NW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = lane * 4 + 256 * i;
+            w2[c][i] = (j < P.J[2] && k < P.J[1]) ? *reinterpret_cast<const float4*>(P.w[2] + (int64_t)j * P.J[1] + k) : z4;
+        }
     }
-    w3 = (gw < P.J[3] && lane * 4 < P.J[2]) ? *reinterpret_cast<const float4*>(P.w[3] + (int64_t)gw * P.J[2] + lane * 4) : z4;
+#pragma unroll
+    for (int c = 0; c < C3; ++c) {
+        const int j = gw + c * NW;
+        w3[c] = (j < P.J[3] && lane * 4 < P.J[2]) ? *reinterpret_cast<const float4*>(P.w[3] + (int64_t)j * P.J[2] + lane * 4) : z4;
+    }
+
+    // one layer: columns j = gw + c NW from the prefetched fragments WF[c][i] (NI float4 per column), epilogue, sc1 store
+#define GN_MLP_LAYER(L, NC, NI, WF)                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                                    \
+        const int j = gw + c * NW;                                                                                      \
+        if (j < P.J[L]) {                                                                                               \
+            float acc[MR];                                                                                              \
+            _Pragma("unroll") for (int m = 0; m < MR; ++m) acc[m] = 0.f;                                                \
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                            \
+                const int k = lane * 4 + 256 * i;                                                                       \
+                if (k < K) {                                                                                            \
+                    _Pragma("unroll") for (int m = 0; m < MR; ++m)                                                      \
+                        acc[m] += dot4(WF, *reinterpret_cast<const float4*>(&xs[m * KMAX + k]));                        \
+                }                                                                                                       \
+            }                                                                                                           \
+            float mine = 0.f;                                                                                           \
+            _Pragma("unroll") for (int m = 0; m < MR; ++m) {                                                            \
+                const float v = wave_sum_dpp(acc[m]);                                                                   \
+                if (lane == m) mine = v;                                                                                \
+            }                                                                                                           \
+            if (lane < P.n) {                                                                                           \
+                float v = mine + P.b[L][j];                                                                             \
+                float g = v > 0.f ? 1.f : 0.f;                                                                          \
+                v = v > 0.f ? v : 0.f;                                                                                  \
+                if (P.mask[L]) { const float mk = P.mask[L][(int64_t)lane * P.ldmask[L] + j]; v *= mk; g *= mk; }       \
+                st_dev(&P.h[L][(int64_t)lane * P.J[L] + j], v);                                                         \
+                if (P.mult[L]) P.mult[L][(int64_t)lane * P.J[L] + j] = g;                                               \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
 
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? P.K0 : P.J[l - 1];
-        const int J = P.J[l];
         if (l == 0) {
             const int kq = K >> 2;
             for (int i = tid; i < MR * kq; i += 256) {
@@ -102,44 +144,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFwdP P) {
             }
         }
         __syncthreads();
-        const int ncols = l < 2 ? 2 : 1;
-        for (int c = 0; c < ncols; ++c) {
-            const int j = gw + c * NW;
-            if (j >= J) break;
-            float acc[MR];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int k = lane * 4 + 256 * i;
-                if (k >= K) break;
-                float4 w4;
-                if (l == 0) w4 = c == 0 ? w0[0][i] : w0[1][i];
-                else if (l == 1) w4 = i < 2 ? (c == 0 ? w1[0][i] : w1[1][i]) : z4;
-                else if (l == 2) w4 = i < 2 ? w2[i] : z4;
-                else w4 = w3;
-#pragma unroll
-                for (int m = 0; m < MR; ++m) acc[m] += dot4(w4, *reinterpret_cast<const float4*>(&xs[m * KMAX + k]));
-            }
-            float mine = 0.f;
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const float v = wave_sum_dpp(acc[m]);
-                if (lane == m) mine = v;
-            }
-            if (lane < P.n) {
-                float v = mine + P.b[l][j];
-                float g = v > 0.f ? 1.f : 0.f;
-                v = v > 0.f ? v : 0.f;
-                if (P.mask[l]) { const float mk = P.mask[l][(int64_t)lane * P.ldmask[l] + j]; v *= mk; g *= mk; }
-                st_dev(&P.h[l][(int64_t)lane * J + j], v);           // the next layer's input, read by every block
-                if (P.mult[l]) P.mult[l][(int64_t)lane * J + j] = g;
-            }
-        }
+        if (l == 0) { GN_MLP_LAYER(0, C0, 3, w0[c][i]) }
+        else if (l == 1) { GN_MLP_LAYER(1, C0, 2, w1[c][i]) }
+        else if (l == 2) { GN_MLP_LAYER(2, C2, 2, w2[c][i]) }
+        else { GN_MLP_LAYER(3, C3, 1, w3[c]) }
         grid_arrive(P.sync);
         if (l == 3 && blockIdx.x != 0) break;                  // the head runs in block 0 only
         if (!grid_wait(P.sync, l + 1, gridDim.x)) return;
     }
+#undef GN_MLP_LAYER
     if (blockIdx.x == 0) {
         // head (utils.py:255-256, 270): z = h4 . w12 + b12; out = 4 sigmoid(z) + 1. One wave per row.
         const int K = P.J[3];
@@ -343,12 +356,18 @@ int goalnet_mlp_fwd(const float* cat, int64_t ldcat, int K0, const float* const*
     GN_REQUIRE(!labels || (loss || dout), GOALNET_E_NULL, "mlp_fwd: labels without a loss / dout destination");
     P.logit = logit; P.out = out; P.labels = labels; P.loss = loss; P.dout = dout; P.n = n; P.sync = sync;
     hipStream_t st = (hipStream_t)stream;
+    static const int fb = getenv("GOALNET_MLP_FWD_BLOCKS") ? atoi(getenv("GOALNET_MLP_FWD_BLOCKS")) : MLP_FWD_BLOCKS;      // 16 | 32 | 64 (A/B runs)
+#define GN_MLP_FWD(MRV)                                                                                       \
+    if (fb == 16) hipLaunchKernelGGL((mlp_fwd_kernel<MRV, 16>), dim3(16), dim3(256), 0, st, P);              \
+    else if (fb == 32) hipLaunchKernelGGL((mlp_fwd_kernel<MRV, 32>), dim3(32), dim3(256), 0, st, P);        \
+    else hipLaunchKernelGGL((mlp_fwd_kernel<MRV, 64>), dim3(64), dim3(256), 0, st, P);
     switch (rows_class(n)) {
-        case 4: hipLaunchKernelGGL(mlp_fwd_kernel<4>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
-        case 8: hipLaunchKernelGGL(mlp_fwd_kernel<8>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
-        case 12: hipLaunchKernelGGL(mlp_fwd_kernel<12>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
-        default: hipLaunchKernelGGL(mlp_fwd_kernel<16>, dim3(MLP_BLOCKS), dim3(256), 0, st, P); break;
+        case 4: GN_MLP_FWD(4) break;
+        case 8: GN_MLP_FWD(8) break;
+        case 12: GN_MLP_FWD(12) break;
+        default: GN_MLP_FWD(16) break;
     }
+#undef GN_MLP_FWD
     GN_LAUNCH_CHECK("mlp_fwd");
     return 0;
 }

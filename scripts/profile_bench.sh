@@ -6,7 +6,7 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="${BENCH_ARGS:---steps 2 --warmup 2 --no-cpu-baseline --no-native40 --no-second-path --dtype ${BENCH_DTYPE:-f32}}"
+ARGS="${BENCH_ARGS:---steps 2 --warmup 2 --no-cpu-baseline --no-native40 --no-second-path --no-live-traffic --dtype ${BENCH_DTYPE:-f32}}"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $ROOT/bench.py $ARGS > $OUT/prof_stats.json 2> $OUT/prof_stats.err || exit 1
 if [ "$1" == "pmc" ]; then
