@@ -15,7 +15,9 @@ namespace {
 
 constexpr int KT = 512;      // forward: K-slab per block (x slab in LDS: MR x KT floats = 24..32 KB -> 5..6 blocks per CU)
 // forward: a block computes 4 waves x CW columns x RN rounds. Long reductions (linear5: 81 K-slabs): CW = 4, RN = 1 (16 columns:
-// 2 592 blocks of ~100 VGPRs; RN = 2 measured 38 us against 35.5). The small layers (fusion MLP, AudBl linear: <= 2 K-slabs) had grids of 4 - 32
+// 2 592 blocks of ~100 VGPRs; RN = 2 measured 38 us against 35.5; round 3: four consecutive K-slabs per block with the next slab's
+// weights prefetched and ONE set of wave reductions per block — 672 blocks — measured 69 us: at this size more blocks with one
+// memory round trip each beat fewer blocks with several). The small layers (fusion MLP, AudBl linear: <= 2 K-slabs) had grids of 4 - 32
 // blocks that way and ran ~10 us each on a sixteenth of the chip: CW = 1, RN = 1 (4 columns per block, 32 - 128 blocks).
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
