@@ -481,6 +481,27 @@ def dropin_path(dev, h, n, steps, warmup):
     t_drop = (time.perf_counter() - t0) / steps
     del optimizer, frame_importance_model
     torch.cuda.empty_cache()
+    # the same loop with ONE changed line: optimizer = model.make_optimizer(lr) (cvml_goalnet_amd.optim.Adam: one fused pass over the arena)
+    torch.manual_seed(4321)
+    fm = AVM(audio_included=True, device=dev)
+    opt2 = fm.make_optimizer(lr=0.001)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            opt2.zero_grad()
+            pr = fm(sub_audios, sub_frames)
+            ls = criterion(pr, sub_labels)
+            ls.backward()
+            opt2.step()
+            batch_loss += ls.item()
+            batch_predictions.extend(pr.flatten().tolist())
+    torch.cuda.synchronize()
+    t_drop_fused_adam = (time.perf_counter() - t0) / steps
+    del opt2, fm
+    torch.cuda.empty_cache()
     torch.manual_seed(4321)
     m = AVM(audio_included=True, device=dev)
     a, v, l = sub_audios.to(dev), sub_frames.to(dev), sub_labels.to(dev)
@@ -493,7 +514,8 @@ def dropin_path(dev, h, n, steps, warmup):
     t_fused = (time.perf_counter() - t0) / steps
     del m
     torch.cuda.empty_cache()
-    return {"frames_per_step": n, "h": h, "w": h, "steps": steps, "dropin_us_per_step": 1e6 * t_drop, "fused_train_step_us_per_step": 1e6 * t_fused,
+    return {"frames_per_step": n, "h": h, "w": h, "steps": steps, "dropin_us_per_step": 1e6 * t_drop,
+            "dropin_with_goalnet_adam_us_per_step": 1e6 * t_drop_fused_adam, "fused_train_step_us_per_step": 1e6 * t_fused,
             "dropin_frames_per_s": n / t_drop, "last_loss": subbatch_loss.item(),
             "what": "main.py:187-196 verbatim (CPU tensors, nn.MSELoss, autograd, stock optim.Adam over 30 strided views, .item() + .tolist()) vs "
                     "AVM.train_step on device tensors, eager launches (no graph)"}

@@ -7,5 +7,6 @@ surface. See DESIGN.md / INTEGRATION.md.
 from . import synth  # noqa: F401
 from ._lib import GoalnetError, LIB_PATH  # noqa: F401
 from .avm import AVM  # noqa: F401
+from . import optim  # noqa: F401
 
-__all__ = ["AVM", "GoalnetError", "synth", "LIB_PATH"]
+__all__ = ["AVM", "GoalnetError", "synth", "LIB_PATH", "optim"]

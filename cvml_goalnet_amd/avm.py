@@ -1199,6 +1199,11 @@ class AVM(nn.Module):
         if _tick:
             ops.counter_add(self._state[0], 1)
 
+    def make_optimizer(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """`optim.Adam(model.parameters(), lr)` (main.py:70) as one fused pass over the arena: cvml_goalnet_amd.optim.Adam"""
+        from .optim import Adam
+        return Adam(self.parameters(), lr=lr, betas=betas, eps=eps, model=self)
+
     def predict_classes(self, scores: torch.Tensor) -> torch.Tensor:
         """head="classifier": `torch.argmax(predictions, axis = 1) + 1` (main.py:97, 190) on the device; (N,) float classes 1..C"""
         s = scores.detach().to(device=self._device, dtype=F32).contiguous()
