@@ -254,3 +254,20 @@ def test_param_sync_and_sharded_linear5_world2_gloo(tmp_path):
         assert r[k]["opt_owner0"] == (0.5, 0.25), "rank 0's Adam moments must reach a rank that had none"
         assert r[k]["opt_owner1"] is None, "rank 0 has no optimizer state: a rank that had some starts without it too"
     assert shard_bounds(0, 1000, 8, 3) is None and shard_bounds(64, 64 + 8 * 128, 8, 3) == (64 + 3 * 128, 64 + 4 * 128)
+
+
+def test_fused_adam_optimizer_can_be_created_before_the_first_forward():
+    """cvml_goalnet_amd.optim.Adam mirrors `optim.Adam(model.parameters(), lr)` at main.py:70: it is constructed while the parameters are
+    still Lazy (no GPU needed), refuses to step without gradients, and insists on the whole parameter set of its AVM."""
+    import pytest
+    from cvml_goalnet_amd.optim import Adam
+    m = AVM(audio_included=True)
+    opt = m.make_optimizer(lr=0.001)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups[0]["params"]) == 30
+    opt.zero_grad()
+    with pytest.raises(RuntimeError):
+        opt.step()
+    with pytest.raises(RuntimeError):
+        Adam(m.parameters(), lr=0.001).step()            # no model given
+    with pytest.raises(ValueError):
+        Adam(m.parameters(), lr=-1.0, model=m)
