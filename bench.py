@@ -364,7 +364,7 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
     """The same workload, K and W on the other engine (N = 1 only): its own ms/step, roofline and parity."""
     from cvml_goalnet_amd import AVM, synth
     torch.manual_seed(1234)
-    model = AVM(audio_included=audio, device=dev, seed=seed, precision={"bf16": "bf16", "fp16": "fp16"}.get(dtype, "fp32"))
+    model = AVM(audio_included=audio, device=dev, seed=seed, precision={"bf16": "bf16", "fp16": "fp16", "bf16x6": "bf16x6"}.get(dtype, "fp32"))
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if not audio:
         aud = None
@@ -374,7 +374,18 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
         parity.update({"weights": "random init (before the first optimizer step)", "dropout": "masks from seed formula", "bn": "train"})
         torch.cuda.empty_cache()
     dt, events, loss = timed_steps(model, aud, vis, lab, warmup, steps, False, dev)
-    roof, others = roofline_of(events, "bf16" if dtype == "fp16" else dtype, n, h, w, clips)
+    roof, others = roofline_of(events, "bf16" if dtype in ("fp16", "bf16x6") else dtype, n, h, w, clips)
+    if roof is not None and dtype == "bf16x6":
+        # six partial products per product: the matrix cores execute 6 x the algorithmic flops; the roofline counts THOSE against the
+        # 16-bit peak, `useful_tflops` is the convolution's own flop count per second (what the fp32 MFMA delivers at <= 157.3)
+        roof["useful_tflops"] = roof["achieved"]
+        roof["achieved"] = 6.0 * roof["useful_tflops"]
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["mfma_flops_per_launch"] = 6.0 * roof["algorithmic_flops_per_launch"]
+        roof["kernel"] += "; split operands [hi | mid | lo], six K-segments per launch (csrc/split3.hip)"
+        roof["traffic"], roof["traffic_source"] = None, "no counter pass for the split-operand launches"
+        for v in others.values():
+            v["useful_tflops"] = v["tflops"]
     if roof is not None and dtype == "fp16":
         roof["kernel"] = roof["kernel"].replace("gemm_bf16_256_kernel<", "gemm_bf16_256_kernel<(F16 = true) ")
         bt = _LIVE_TRAFFIC.get("bf16", (None, None))
@@ -385,7 +396,11 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
            "arithmetic": (f"{dtype} MFMA contractions (conv2/conv3 fwd+dgrad+wgrad, linear5), {dtype} storage of the activations between them; "
                           "fp32 accumulation, BatchNorm statistics, block 1, AudBl, fusion MLP, loss, gradients, master weights, Adam"
                           + ("; loss scale 2^(10 + ceil(log2 n)) on dL/dpred with an overflow guard in the fused Adam" if dtype == "fp16" else ""))
-                         if dtype != "f32" else "fp32 MFMA everywhere (the reference's arithmetic)"}
+                         if dtype not in ("f32", "bf16x6") else
+                         ("fp32 storage and arithmetic as the fp32 path, except conv2 forward and conv3 forward / data gradient / weight gradient: their "
+                          "fp32 operands are split into bf16 triples hi + mid + lo (exact) and multiplied as six partial products on the 16-bit MFMA "
+                          "with fp32 accumulation (csrc/split3.hip); held to the fp32 engine's parity criteria (tests/test_gpu_bench_shapes.py)"
+                          if dtype == "bf16x6" else "fp32 MFMA everywhere (the reference's arithmetic)")}
     if dtype == "fp16":
         out["overflow_skipped_steps"] = int(model._guard[1].item())
     if parity is not None:
@@ -692,8 +707,8 @@ def main():
             del model, aud, vis, lab
             torch.cuda.empty_cache()
             if not args.no_second_path:
-                for other in (("bf16", "fp16") if args.dtype == "f32" else ("f32",)):
-                    key = {"bf16": "bf16_path", "fp16": "fp16_path", "f32": "fp32_path"}[other]
+                for other in (("bf16x6", "bf16", "fp16") if args.dtype == "f32" else ("f32",)):
+                    key = {"bf16": "bf16_path", "fp16": "fp16_path", "f32": "fp32_path", "bf16x6": "bf16x6_path"}[other]
                     try:
                         res[key] = reduced_precision_path(dev, other, n, h, w, not args.no_audio, seed, args.steps, args.warmup, args.clips,
                                                           not args.no_cpu_baseline)

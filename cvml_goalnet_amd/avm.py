@@ -137,8 +137,13 @@ class AVM(nn.Module):
             raise ValueError("num_classes must be in 2..8")
         self.head = head
         self.num_classes = num_classes if head == "classifier" else 1
-        if precision not in ("fp32", "bf16", "fp16"):
-            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16' or 'fp16' (16-bit MFMA contractions)")
+        if precision not in ("fp32", "bf16", "fp16", "bf16x6"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16x6' (fp32 operands as bf16 triples on the 16-bit "
+                             "MFMA), 'bf16' or 'fp16' (16-bit MFMA contractions)")
+        # "bf16x6": everything is stored and computed as under "fp32" except the large 3 x 3 convolutions (conv2 forward; conv3 forward,
+        # data gradient and weight gradient at >= 65 536 output pixels), whose fp32 operands are split into bf16 triples hi + mid + lo
+        # (exact) and multiplied as six partial products on the 16-bit MFMA with fp32 accumulation (csrc/split3.hip): fp32-grade
+        # results (3-4 x the rounding error of the fp32 MFMA's own accumulation) at 1.4-1.65 x its speed.
         # "bf16" / "fp16": the dense contractions (conv2/conv3 forward + data / weight gradient, linear5) run on the 16-bit matrix
         # cores with fp32 accumulation; statistics, master weights, parameter gradients and Adam stay fp32.
         # fp16 keeps 11 significand bits against bf16's 8 (~8 x less rounding noise in the logits) but has 5 exponent bits:
@@ -219,10 +224,11 @@ class AVM(nn.Module):
 
     @precision.setter
     def precision(self, value: str):
-        if value not in ("fp32", "bf16", "fp16"):
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+        if value not in ("fp32", "bf16", "fp16", "bf16x6"):
+            raise ValueError("precision must be 'fp32', 'bf16x6', 'bf16' or 'fp16'")
         self._precision = value
         self._half = value in ("bf16", "fp16")
+        self._x6 = value == "bf16x6"                                          # split-operand convolutions (csrc/split3.hip); fp32 storage
         self._h16 = torch.float16 if value == "fp16" else torch.bfloat16     # the 16-bit storage format of the GEMM operands
         self._w5b, self._w5b_version = None, None                              # a copy in the other format is not reusable
         self._padbufs, self._padgen = {}, {}                                   # nor are the cached padded 16-bit operand buffers
@@ -554,6 +560,14 @@ class AVM(nn.Module):
         pooled activation the fused backward can read back"""
         return c % 32 == 0 and 3 * wc * 32 * 4 <= 65536 and AVM._bwd16_ok(wc)
 
+    def _x6_conv(self, m, cout):
+        """precision="bf16x6": does this convolution (m output pixels, cout output channels of the GEMM) run on split operands?
+        Only where the 256 x 256 tile is filled; everything else runs the fp32-MFMA kernels."""
+        return self._x6 and m >= 65536 and cout >= 256 and os.environ.get("GOALNET_X6_OFF") != "1"
+
+    def _split_w(self, w, rows, c):
+        return ops.split3_rows(w, torch.empty(rows * 3 * c, dtype=torch.bfloat16, device=w.device), rows, c)
+
     def _mlp_fused(self, n):
         """the one-launch fusion MLP (csrc/mlp.hip): the regression head at the reference's sub-batch sizes"""
         return n <= 16 and self.head == "regression" and os.environ.get("GOALNET_MLP_FUSED", "1") != "0"
@@ -651,6 +665,11 @@ class AVM(nn.Module):
             w2b = ops.cast_bf16(P("visbl.conv2.weight"), torch.empty(256 * 9 * 64, dtype=BF16, device=dev))
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16p_o16 if y16_2 else ops.conv3x3_fwd_bf16p,
                         xh1, w2b, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+        elif self._x6_conv(n * hp1 * wp1, 256):
+            x1s = ops.split3_padded(p1, st1[2], st1[3], self._padbuf("x1s" if save else "x1se", n, hp1, wp1, 192), n, hp1, wp1, 64)
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_x6,
+                        x1s, self._split_w(P("visbl.conv2.weight"), 256 * 9, 64), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
+            del x1s                                  # conv2's weight gradient stays on the fp32 kernel (3 output tiles: no gain)
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
@@ -667,6 +686,13 @@ class AVM(nn.Module):
             w3b = ops.cast_bf16(P("visbl.conv3.weight"), torch.empty(512 * 9 * 256, dtype=BF16, device=dev))
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16p_o16 if y16_3 else ops.conv3x3_fwd_bf16p,
                         xh2, w3b, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+        elif self._x6_conv(n * hp2 * wp2, 256):
+            x2s = ops.split3_padded(p2, st2[2], st2[3], self._padbuf("x2s" if save else "x2se", n, hp2, wp2, 768), n, hp2, wp2, 256)
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_x6,
+                        x2s, self._split_w(P("visbl.conv3.weight"), 512 * 9, 256), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+            if save:
+                ctx.update(x2s=x2s, x2s_gen=self._padgen["x2s"])
+            del x2s
         else:
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
@@ -903,10 +929,19 @@ class AVM(nn.Module):
         dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
         del dbn3
         st2 = ctx["st2"]
+        x6_3 = "x2s" in ctx                          # precision="bf16x6" and the forward ran conv3 on split operands
         if bf:
             dyp3 = dy3
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
                                          ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
+        elif x6_3:
+            if ctx["x2s_gen"] != self._padgen["x2s"]:
+                raise RuntimeError("precision='bf16x6': a second training-mode forward overwrote the saved split operands before "
+                                   "backward ran; call backward after each forward (as the reference's loop does)")
+            # the weight gradient and the data gradient read the gradient as bf16 triples in the padded layout: one split pass
+            dys3 = ops.split3_padded(dy3, None, None, self._padbuf("dy3s", n, hp2, wp2, 1536), n, hp2, wp2, 512)
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_x6,
+                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dys3)
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
                                          ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
@@ -925,6 +960,10 @@ class AVM(nn.Module):
             else:
                 self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
                             dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
+        elif x6_3:
+            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_x6,
+                        dys3, self._split_w(wt, 256 * 9, 512), None, False, dbn2, n, hp2, wp2, 512, 256)
+            del dys3
         else:
             self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
                         dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)

@@ -27,6 +27,18 @@
 // Staging order (slot freed one phase earlier): (t,q0) A1 of t+1 | (t,q1) A0 of t+2 | (t,q2) B0 of t+2 | (t,q3) B1 of t+2.
 // K-tiles past the end are still "staged" (out-of-range addresses return zeros or unused data) so the counts stay
 // uniform; they are never multiplied.
+//
+// Tile sequence (round 3). One block per CU is launched and WALKS the tiles (virtual block L, L + G, ...; G a multiple of 8,
+// so every tile stays on the XCD — the L2 — a one-block-per-tile launch would have given it). After a tile's last phase
+// the LDS is free, so the next tile's prologue (14 DMA loads per wave) is issued BEFORE the epilogue and flies under it;
+// the bias of the next tile's columns is fetched there too. In-kernel stamps (scripts/stamps_conv.py, conv3 forward, random
+// operands): tile period 66.7 us = main loop 57.5 + prologue issue / MFMA drain 2.1 + epilogue 4.3 + waves re-joining 1.9
+// + bias 0.7 + 0.2; the one-block-per-tile form paid a block dispatch, the loaders' set-up and the first DMA latency
+// in front of every tile (~3 us more). The convolution forward / data gradient feed the MFMA (B, A) instead of (A, B): the
+// accumulators hold C^T blocks, a lane owns 4 consecutive columns of one output row, and the epilogue packs and stores
+// without transposing (SWAP below; bit-identical results, scripts/probe/swap_hash.py). What is left of the epilogue is
+// the stores themselves: the CUs run in step, so 256 x 128 KB leave at the same time (a store pattern of whole 128-B lines
+// per 8 lanes, tried as a timing experiment, moved the total by < 1 us).
 #include "gemm_bf16_common.h"
 
 using namespace goalnet;
@@ -41,16 +53,39 @@ constexpr int LDS_BYTES = 2 * 4 * HALF_BYTES;
 template <int GROUP>
 __device__ __forceinline__ int tile_row_of(int h, int lr) { return (lr / GROUP) * (2 * GROUP) + h * GROUP + (lr % GROUP); }
 
+// ---- split operands ("bf16x6", fp32 products from 16-bit MFMAs) --------------------------------------------------------
+// An fp32 value v is stored as three bf16 values hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): v = hi + mid + lo
+// exactly (3 x 8 significand bits). A product a b is then the sum of nine exact 16-bit products; the three smallest
+// (mid lo, lo mid, lo lo: < 2^-23 |a b|) are dropped and the other six are six K-segments of ONE 16-bit GEMM with fp32
+// accumulation — the same kernel, 6 x the K-tiles, on operands stored [hi | mid | lo] along the channel axis. Segment s reads
+// part (map >> 4 s) & 15 of its operand; the small terms come first:
+//        s:   0          1         2         3          4          5
+//   A part:  mid        hi        lo        hi         mid        hi          SEGMAP_A = 0x010201
+//   B part:  mid        lo        hi        mid        hi         hi          SEGMAP_B = 0x001021
+constexpr unsigned SEGMAP_A = 0x010201u, SEGMAP_B = 0x001021u;
+// The segments are the FAST index of the reduction: virtual chunk = 6 * (64-channel chunk) + s (convolutions), K-tile =
+// 6 * (64-pixel tile) + s (weight gradient), so that the six products of one piece of the operands run back to back and its
+// parts are fetched from HBM once (with the segment as the slow index every part was streamed two to three times:
+// conv3's weight gradient 78.9 ms).
+// first stored channel of virtual 64-channel chunk `chunk` (segC channels per part); past the end: >= 3 segC or harmless
+__device__ __forceinline__ int seg_channel(int chunk, int segC, unsigned segmap) {
+    const int cc = chunk / 6, seg = chunk - 6 * cc;
+    return (int)((segmap >> (4 * seg)) & 15u) * segC + cc * BKH;
+}
+
 // K-contiguous bf16 matrix X[rows][K] (weights [Cout][9*Cin]); wave w issues pieces 2w, 2w+1 of a half-tile
-template <int GROUP>
+template <int GROUP, bool SEG = false>
 struct KCLoader256 {
-    struct P { const __hip_bfloat16* x; int64_t ld; int rows; int convC; };      // convC > 0: K-tiles in (channel chunk, tap) order
+    // convC > 0: K-tiles in (channel chunk, tap) order over rows of 9 x convC values. segC > 0 (split operands, SegMap below):
+    // convC = 3 segC stored channels [hi | mid | lo] per tap, 6 segC virtual ones
+    struct P { const __hip_bfloat16* x; int64_t ld; int rows; int convC; int segC; unsigned segmap; };
     static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
-    int wave, convC;
+    int wave, convC, segC;
+    unsigned segmap;
     __device__ KCLoader256(const P& p, int row0, int tid) {
-        convC = p.convC;
+        convC = p.convC; segC = p.segC; segmap = p.segmap;
         const int nrows = p.rows - row0 < T ? p.rows - row0 : T;
         rx = make_rsrc(p.x + (int64_t)row0 * p.ld, clamp_u32((int64_t)nrows * p.ld * 2));
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +102,8 @@ struct KCLoader256 {
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
         // the k range of K-tile kt: plain = [64 kt, +64); convolution order = tap (kt % 9), channels 64 (kt / 9) .. +63
-        const unsigned koff = convC > 0 ? (unsigned)((kt % 9) * convC + (kt / 9) * BKH) : (unsigned)kt * BKH;
+        unsigned koff = convC > 0 ? (unsigned)((kt % 9) * convC + (kt / 9) * BKH) : (unsigned)kt * BKH;
+        if constexpr (SEG) koff = (unsigned)((kt % 9) * convC + seg_channel(kt / 9, segC, segmap));
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], koff * 2);
     }
@@ -75,15 +111,16 @@ struct KCLoader256 {
 
 // im2col of a zero-padded bf16 NHWC tensor (buffer convention of gemm_bf16.hip: `x` = padded pixel 0, W+3 zero guard pixels
 // in front and behind): row m = (n,h,w) of the output grid, k = (kh,kw,ci); no validity masks.
-template <int GROUP>
+template <int GROUP, bool SEG = false>
 struct ConvAPadLoader256 {
-    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; };
+    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; int segC; unsigned segmap; };   // segC > 0: C = 3 segC stored channels (split operands)
     static constexpr bool TR = false;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
-    int Wp2, C, wave;
+    int Wp2, C, wave, segC;
+    unsigned segmap;
     __device__ ConvAPadLoader256(const P& p, int row0, int tid) {
-        Wp2 = p.W + 2; C = p.C;
+        Wp2 = p.W + 2; C = p.C; segC = p.segC; segmap = p.segmap;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
         const int hw = p.H * p.W;
@@ -115,7 +152,8 @@ struct ConvAPadLoader256 {
         // L2. With taps outermost the reuse distance was a whole sweep over the channels of every resident block (8 MB per
         // XCD at C = 512) and the data gradient re-fetched its input 5x from the fabric (profiles/r01_bf16_traffic.md).
         const int chunk = kt / 9, tap = kt - 9 * chunk;
-        const int ci = chunk * BKH;
+        int ci = chunk * BKH;
+        if constexpr (SEG) ci = seg_channel(chunk, segC, segmap);
         const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                  // tap / 3 for tap < 16
         // past the last K-tile (ci >= C) the offset only has to stay harmless: the range check turns it into zeros
         const unsigned s0 = ci < C ? (unsigned)(((kh * Wp2 + kw) * C + ci) * 2) : OOB;
@@ -172,15 +210,19 @@ __device__ __forceinline__ bf16x8 rd_tr(const unsigned (&ad)[2]) {
     DST[2] = rd_tr<(S) * HALF_BYTES + 2 * 16 * TROWB>(AD); DST[3] = rd_tr<(S) * HALF_BYTES + 3 * 16 * TROWB>(AD);
 
 // plain matrix X[kred][cols] (dy_pad [pixels][Cout]): re-based every K-tile; rows past kred / columns past `cols` read 0
-struct MCLoader256 {
-    struct P { const __hip_bfloat16* x; int64_t ld; int cols; int64_t kred; };
+template <bool SEG>
+struct MCLoader256T {
+    // SEG (split operands, segKT > 0): K-tile kt = 6 * (64-row tile) + segment s; segment s reads the columns of part
+    // (segmap >> 4 s) & 15, segC columns further right each (ld = 3 segC)
+    struct P { const __hip_bfloat16* x; int64_t ld; int cols; int64_t kred; int segKT; int segC; unsigned segmap; };
     static constexpr bool TR = true;
     const __hip_bfloat16* x;
     int64_t ld, kred;
-    int wave;
+    int wave, segKT, segC;
+    unsigned segmap;
     unsigned voff[2][2];
-    __device__ MCLoader256(const P& p, int col0, int tid) {
-        x = p.x; ld = p.ld; kred = p.kred;
+    __device__ MCLoader256T(const P& p, int col0, int tid) {
+        x = p.x; ld = p.ld; kred = p.kred; segKT = p.segKT; segC = p.segC; segmap = p.segmap;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
 #pragma unroll
@@ -193,26 +235,34 @@ struct MCLoader256 {
             }
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
-        const int64_t kbase = (int64_t)kt * BKH;
+        int kk = kt;
+        unsigned soff = 0u;
+        if constexpr (SEG) { kk = kt / 6; soff = ((segmap >> (4 * (kt - 6 * kk))) & 15u) * (unsigned)segC * 2u; }
+        const int64_t kbase = (int64_t)kk * BKH;                             // past the last tile: empty range below
         const int64_t nk = kred - kbase < BKH ? kred - kbase : BKH;          // <= 0 past the end: empty range, zeros
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + kbase * ld, clamp_u32(nk * ld * 2));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], 0);
+        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], soff);
     }
 };
+
+typedef MCLoader256T<false> MCLoader256;
 
 // B operand of the weight gradient on the zero-padded pixel grid: B(col = (tap, ci), k = pm) = x_pad[pm + shift(tap)][ci]
 // (constant pixel shift per tap; pad pixels contribute nothing because dy_pad is zero there). `x` = padded pixel 0 of a
 // buffer with W+3 zero guard pixels in front and behind.
-struct ConvWgradBLoader256 {
-    struct P { const __hip_bfloat16* x; int Wp2, C; int64_t Mp; };
+template <bool SEG>
+struct ConvWgradBLoader256T {
+    // SEG (split operands, segKT > 0): Cs = 3 C stored channels per pixel, K-tile kt = 6 * (64-pixel tile) + segment
+    struct P { const __hip_bfloat16* x; int Wp2, C; int64_t Mp; int Cs; int segKT; unsigned segmap; };
     static constexpr bool TR = true;
     const __hip_bfloat16* x;
     int64_t Mp;
-    int C, G, wave;
+    int C, G, wave, Cs, segKT;
+    unsigned segmap;
     unsigned voff[2][2];
-    __device__ ConvWgradBLoader256(const P& p, int col0, int tid) {
-        x = p.x; C = p.C; G = p.Wp2 + 1; Mp = p.Mp;
+    __device__ ConvWgradBLoader256T(const P& p, int col0, int tid) {
+        x = p.x; C = p.C; G = p.Wp2 + 1; Mp = p.Mp; Cs = p.Cs; segKT = p.segKT; segmap = p.segmap;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lane = tid & 63;
 #pragma unroll
@@ -224,20 +274,24 @@ struct ConvWgradBLoader256 {
                 if (col < 9 * p.C) {
                     const int tap = col / p.C, ci = col - tap * p.C;
                     const int kh = tap / 3, kw = tap - 3 * kh;
-                    voff[h][i] = (unsigned)(((kr + kh * p.Wp2 + kw) * p.C + ci) * 2);       // relative to pixel (kbase - G)
+                    voff[h][i] = (unsigned)(((kr + kh * p.Wp2 + kw) * p.Cs + ci) * 2);      // relative to pixel (kbase - G)
                 } else {
                     voff[h][i] = OOB;
                 }
             }
     }
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
-        const int64_t kbase = (int64_t)kt * BKH;
+        int kk = kt;
+        unsigned soff = 0u;
+        if constexpr (SEG) { kk = kt / 6; soff = ((segmap >> (4 * (kt - 6 * kk))) & 15u) * (unsigned)C * 2u; }
+        const int64_t kbase = (int64_t)kk * BKH;
         // K-tiles past the pixel grid (staged only to keep the DMA counts uniform) get an empty range: zeros, no access
-        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (kbase - G) * C, kbase < Mp ? (uint32_t)((BKH + 2 * G) * C * 2) : 0u);
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (kbase - G) * Cs, kbase < Mp ? (uint32_t)((BKH + 2 * G) * Cs * 2) : 0u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], 0);
+        for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], soff);
     }
 };
+typedef ConvWgradBLoader256T<false> ConvWgradBLoader256;
 
 __device__ __forceinline__ bf16x8 read_frag(const char* half, int row0, int ks, int lane) {
     return *reinterpret_cast<const bf16x8*>(half + kc_boff(row0 + (lane & 31), 2 * ks + (lane >> 5)));
@@ -260,16 +314,23 @@ __device__ __forceinline__ void mfma_pinned(f32x16& c, const bf16x8& a, const bf
     if constexpr (TRA || TRB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     /* the asm fragment reads (rd_tr) */ \
     asm volatile("s_barrier\n\ts_setprio 1" ::: "memory");                         \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                      \
-        mfma_pinned<F16>(ACC0, AF[0][ks], BF[ks]);                                                          \
-        mfma_pinned<F16>(ACC1, AF[1][ks], BF[ks]);                                                          \
+        if constexpr (SWAP) { mfma_pinned<F16>(ACC0, BF[ks], AF[0][ks]); mfma_pinned<F16>(ACC1, BF[ks], AF[1][ks]); } \
+        else { mfma_pinned<F16>(ACC0, AF[0][ks], BF[ks]); mfma_pinned<F16>(ACC1, AF[1][ks], BF[ks]); }      \
     }                                                                                                       \
     asm volatile("s_setprio 0\n\ts_barrier" ::: "memory");
 
+// roles whose launch is persistent (one block per CU walking the tiles); see launch_256_t for the measurements
+constexpr bool walks_tiles(int role) { return role == 0 || role == 1 || role == 4; }
+
+#ifndef GN_SWAP_OPERANDS
+#define GN_SWAP_OPERANDS 1          // 0: the (A, B) operand order with the transposing epilogue (A/B builds only)
+#endif
 #ifdef GN_STAMPS
 // Diagnostic build only (-DGN_STAMPS, loaded through GOALNET_LIB_PATH by scripts/ablate_conv.py): wave 0 of every block
-// stamps the 100 MHz real-time counter at six points; the stamps go to a buffer nothing else reads.
+// stamps the 100 MHz real-time counter at six points of every tile (0 tile start, 1 bias staged, 2 first operands landed,
+// 3 main loop done, 4 next prologue issued + MFMAs drained, 5 stores issued); the stamps go to a buffer nothing else reads.
 __device__ unsigned long long gn_stamps[6 * 65536];
-#define GN_STAMP(I) if (tid == 0 && blockIdx.x < 65536) gn_stamps[6 * blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime();
+#define GN_STAMP(I) if (tid == 0 && vb < 65536) gn_stamps[6 * vb + (I)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GN_STAMP(I)
 #endif
@@ -278,54 +339,116 @@ __device__ unsigned long long gn_stamps[6 * 65536];
 template <class AL, class BL, int ROLE, bool F16>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap, typename BL::P bp, EpiP ep,
                                                               int tiles_m, int tiles_n, int m_fast, int ktiles_total,
-                                                              int ktiles_per_split) {
+                                                              int ktiles_per_split, int total_blocks) {
     constexpr bool TRA = AL::TR, TRB = BL::TR;      // operand forms: K-contiguous rows (false) or row-contiguous / transposed-read (true)
+    // SWAP: the MFMA takes (B fragment, A fragment), i.e. it computes the 32 x 32 block of C^T. Products and the order of the
+    // K sum are those of (A, B) — the result is bit-identical — but a lane now holds 4 consecutive COLUMNS of one row of C per
+    // register group (row = lane & 31) instead of 4 consecutive rows of one column: the epilogue stores straight from the
+    // accumulators, without the quad transposes that were half of its ~1100 VALU instructions per wave.
+    // Transposed-read operands keep their row / column permutation: it applies to the index inside the 32-block, which SWAP
+    // moves from the lane to the register (columns) and from the register to the lane (rows).
+    // Only the roles with a 16-bit result use it (same box, bench step: conv forward -5.8 %, data gradient -3.0 %, linear5 dX
+    // -2 % together with the tile walk). The fp32 slab roles keep (A, B): their transposed stores are whole 128-B lines per 8
+    // lanes, the swapped form writes 32-B pieces of 32 rows per instruction, and linear5's dW (256 KB of fp32 per 16 K-tiles)
+    // lost 7 % with it; the weight gradient and linear5's forward did not move.
+    constexpr bool SWAP = GN_SWAP_OPERANDS && (ROLE == 0 || ROLE == 1 || ROLE == 4);
+    // WALK: the block goes on to the virtual blocks L + gridDim.x, ... (launch_256_t launches one block per CU for these roles);
+    // the other roles run one tile per block and compile without the hand-over (no register pressure from it, no spills).
+    constexpr bool WALK = walks_tiles(ROLE);
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
-    int tm, tn, split = 0;
-    GN_STAMP(0)
-    if (ROLE == 2 || ROLE == 3) {
-        // weight gradient (and the linear5 forward): few output tiles (18 / 8), many K splits. All tiles of a split read the same pixels, so they run on
-        // ONE XCD back to back (blocks L, L + 8, ... share an XCD): XCD x takes splits x, x + 8, ... and walks their tiles.
-        // Spread over all XCDs, every XCD fetched every pixel: 72 GB/launch from the fabric against 9 GB of operands.
-        const int tiles = tiles_m * tiles_n, nsplit = (int)gridDim.x / tiles;
-        const int L = (int)blockIdx.x, xcd = L & 7, j = L >> 3;
-        if ((nsplit & 7) == 0) { split = xcd + 8 * (j / tiles); const int t = j % tiles; tm = t % tiles_m; tn = t / tiles_m; }
-        else { split = L / tiles; const int t = L % tiles; tm = t % tiles_m; tn = t / tiles_m; }
-    } else {
-        tile_of_block(tiles_m, tiles_n, m_fast, tm, tn);
-    }
-    const AL al(ap, tm * T, tid);
-    const BL bl(bp, tn * T, tid);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int kt0 = split * ktiles_per_split;                           // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
-    const int ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
+    // (tm, tn, split) of virtual block L of `total_blocks`. The launch is PERSISTENT: one block per CU walks the virtual
+    // blocks L = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so a virtual block keeps the XCD the
+    // plain launch gave it, and with it the L2 reuse the mappings below are built for).
+    auto coords = [&](int L, int& tm_, int& tn_, int& split_) {
+        split_ = 0;
+        if (ROLE == 2 || ROLE == 3) {
+            // weight gradient (and the linear5 forward): few output tiles (18 / 8), many K splits. All tiles of a split read the same pixels, so they run on
+            // ONE XCD back to back (blocks L, L + 8, ... share an XCD): XCD x takes splits x, x + 8, ... and walks their tiles.
+            // Spread over all XCDs, every XCD fetched every pixel: 72 GB/launch from the fabric against 9 GB of operands.
+            const int tiles = tiles_m * tiles_n, nsplit = total_blocks / tiles;
+            const int xcd = L & 7, j = L >> 3;
+            if ((nsplit & 7) == 0) { split_ = xcd + 8 * (j / tiles); const int t = j % tiles; tm_ = t % tiles_m; tn_ = t / tiles_m; }
+            else { split_ = L / tiles; const int t = L % tiles; tm_ = t % tiles_m; tn_ = t / tiles_m; }
+        } else {
+            const unsigned v = xcd_remap((unsigned)L, (unsigned)(tiles_m * tiles_n));
+            if (m_fast) { tm_ = (int)(v % (unsigned)tiles_m); tn_ = (int)(v / (unsigned)tiles_m); }
+            else        { tn_ = (int)(v % (unsigned)tiles_n); tm_ = (int)(v / (unsigned)tiles_n); }
+        }
+    };
+    auto slot = [&](int t, int s) -> char* { return lds + ((t & 1) * 4 + s) * HALF_BYTES; };     // s: 0 A0, 1 A1, 2 B0, 3 B1
+    // prologue of a tile: K-tile 0 complete, K-tile 1 without its A1 (phase (0,q0) stages that)
+#define GN_PROLOGUE()                                                                                       \
+    al.issue(kt0 + 0, 0, slot(0, 0)); bl.issue(kt0 + 0, 0, slot(0, 2)); bl.issue(kt0 + 0, 1, slot(0, 3)); al.issue(kt0 + 0, 1, slot(0, 1)); \
+    bl.issue(kt0 + 1, 0, slot(1, 2)); al.issue(kt0 + 1, 0, slot(1, 0)); bl.issue(kt0 + 1, 1, slot(1, 3));
 
-    // The accumulators start at the bias (convolution forward: all 16 registers of acc[.][j] are one output column), so the
-    // epilogue has no add left: it is instruction-bound (in-kernel stamps: 6.5 - 9.7 us of a 68 - 72 us tile; ~1100 VALU
-    // instructions per wave, of which the transposes are half and bias + clamp were a quarter).
+    // bias of the tile's 256 columns (convolution forward). SWAP: register e of acc[.][j] is output column
+    // 32 j + (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the wave's 64 — 32 different values per lane: thread t fetches column t
+    // while the previous tile's epilogue runs (one register), the tile start puts it into LDS (1 KB beside the 128 KB of
+    // operands) and the accumulators are initialised from there. Otherwise all 16 registers of acc[.][j] are column
+    // 32 j + (lane & 31): two registers.
+    __shared__ __attribute__((aligned(16))) float bias_lds[T];
+    float bias_t = 0.f, bias_col[2] = {0.f, 0.f};
+#define GN_LOAD_BIAS()                                                                                      \
+    if constexpr (ROLE == 0) {                                                                              \
+        if constexpr (SWAP) {                                                                               \
+            bias_t = 0.f;                                                                                   \
+            if (ep.bias && tid < T && tn * T + tid < ep.cols) bias_t = ep.bias[tn * T + tid];               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                 \
+                const int colj = tn * T + wc * 64 + j * 32 + (lane & 31);                                   \
+                bias_col[j] = ep.bias && colj < ep.cols ? ep.bias[colj] : 0.f;                              \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    int vb = (int)blockIdx.x;
+    int tm, tn, split;
+    coords(vb, tm, tn, split);
+    GN_LOAD_BIAS()
+    AL al(ap, tm * T, tid);
+    BL bl(bp, tn * T, tid);
+    int kt0 = split * ktiles_per_split;                                 // split-K: this block reduces K-tiles [kt0, kt0 + ktiles)
+    int ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
+    GN_PROLOGUE()
+#define GN_WAIT_KTILE0() asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (SWAP) GN_WAIT_KTILE0()
+  for (;;) {
+    GN_STAMP(0)
+    if constexpr (SWAP && ROLE == 0) {
+        if (tid < T) bias_lds[tid] = bias_t;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    GN_STAMP(1)
+    // K-tile 0 = the 8 oldest of the 14 DMA loads of the prologue: it has landed when at most 6 vector-memory operations
+    // are outstanding (they complete in issue order; anything issued later — spill traffic, epilogue stores — only makes the
+    // counted wait stricter). SWAP: the wave has already waited (GN_WAIT_KTILE0 before the loop / before the previous tile's
+    // stores, so that it does not wait for those stores' acknowledgements here: 1.5 us per tile in the stamps).
+    if constexpr (!SWAP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    // The accumulators start at the bias, so the epilogue has no add left.
     f32x16 acc[4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float b0 = 0.f;
-        if constexpr (ROLE == 0) {
-            const int colj = tn * T + wc * 64 + j * 32 + (lane & 31);
-            if (ep.bias && colj < ep.cols) b0 = ep.bias[colj];
+        if constexpr (SWAP) {
+            f32x16 bj;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (ROLE == 0) b4 = *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5)]);
+                bj[4 * g] = b4.x; bj[4 * g + 1] = b4.y; bj[4 * g + 2] = b4.z; bj[4 * g + 3] = b4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = bj;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = bias_col[j];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = b0;
     }
-
-    auto slot = [&](int t, int s) -> char* { return lds + ((t & 1) * 4 + s) * HALF_BYTES; };     // s: 0 A0, 1 A1, 2 B0, 3 B1
-
-    // prologue: K-tile 0 complete, K-tile 1 without its A1 (phase (0,q0) stages that)
-    al.issue(kt0 + 0, 0, slot(0, 0)); bl.issue(kt0 + 0, 0, slot(0, 2)); bl.issue(kt0 + 0, 1, slot(0, 3)); al.issue(kt0 + 0, 1, slot(0, 1));
-    bl.issue(kt0 + 1, 0, slot(1, 2)); al.issue(kt0 + 1, 0, slot(1, 0)); bl.issue(kt0 + 1, 1, slot(1, 3));
-    GN_STAMP(1)
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     GN_STAMP(2)
     if (wr == 1) asm volatile("s_barrier" ::: "memory");                 // stagger the two wave rows by one barrier
 
@@ -387,14 +510,33 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     }
     GN_STAMP(3)
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
-    // drain: no DMA may land after the block has released its LDS, and the last MFMAs (16 passes) must have written back
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // Every wave has passed the closing barrier of the last phase: all fragment reads of this tile are done and the LDS is
+    // free. The NEXT virtual block's prologue is issued now, so that its DMA flies under this tile's epilogue (the stray
+    // stagings past this tile's last K-tile were issued earlier by the same wave into the same rows: they land first).
+    const int tm_out = tm, tn_out = tn, split_out = split;
+    const int vb_next = vb + (int)gridDim.x;
+    const bool more = WALK && vb_next < total_blocks;
+    if (more) {
+        coords(vb_next, tm, tn, split);
+        al = AL(ap, tm * T, tid);
+        bl = BL(bp, tn * T, tid);
+        kt0 = split * ktiles_per_split;
+        ktiles = min(ktiles_total, kt0 + ktiles_per_split) - kt0;
+        GN_PROLOGUE()
+        GN_LOAD_BIAS()
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no DMA may land after the block has released its LDS
+    }
+    // the last MFMAs (16 passes) must have written back before the epilogue reads the accumulators
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));                    // no DMA may land after the block has released its LDS
 
     GN_STAMP(4)
+    do {                                            // the epilogue of tile (tm_out, tn_out, split_out); `break` = done
+    const int tm = tm_out, tn = tn_out, split = split_out;
     // epilogue (conv forward: bias + ReLU; data gradient: raw; weight gradient / linear5 forward: raw split-K slab).
     // A lane of the 32x32 accumulator holds 4 consecutive ROWS of one column per register group; quad_transpose4
     // (gemm_common.h) turns that into 4 consecutive COLUMNS of one row, i.e. one 16-byte store per lane and whole 128-B lines
@@ -407,6 +549,73 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
         else return v;
     };
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
+    if constexpr (SWAP) {
+        // lane (r, hh) holds, for register group g of acc[mi][ni], columns 32 ni + 8 g + 4 hh .. + 3 of row 32 (mi) + r.
+        // 16-bit result: lanes l and l + 32 hold the two halves of the same 8 columns; ONE v_permlane32_swap per packed
+        // dword gives the lower lane the whole of group 2 gp and the upper lane the whole of group 2 gp + 1: a 16-byte
+        // store per lane, 16 store instructions per wave, ~250 VALU instructions instead of ~1100.
+        __hip_bfloat16* o16 = reinterpret_cast<__hip_bfloat16*>(ep.out16);
+        if (o16) {
+            // all values first (registers only), then the wait for the next tile's first operands, then the stores
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 pk[4][2][2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned x[2], y[2];
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const unsigned p0 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 2 * d]), fin(acc[mi][ni][8 * gp + 2 * d + 1]));
+                            const unsigned p1 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 4 + 2 * d]), fin(acc[mi][ni][8 * gp + 4 + 2 * d + 1]));
+                            // lower lane: (its group 2gp, the upper lane's 2gp); upper lane: (the lower lane's 2gp+1, its 2gp+1)
+                            const auto sw = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
+                            x[d] = sw[0]; y[d] = sw[1];
+                        }
+                        pk[mi][ni][gp] = u32x4{x[0], x[1], y[0], y[1]};
+                    }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) asm volatile("" : "+v"(pk[mi][ni][gp]));          // the packing stays above the wait
+            GN_WAIT_KTILE0()
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t row = (int64_t)tm * T + (TRA ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (r & 15) + 64 * (r >> 4)
+                                                           : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + r);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int col8 = tn * T + (TRB ? ni * 128 + 16 * wc + 64 * gp + 8 * hh : wc * 64 + ni * 32 + 16 * gp + 8 * hh);
+                        if (row < ep.rows && col8 < ep.cols)                                           // cols % 8 == 0
+                            *reinterpret_cast<u32x4*>(o16 + row * ep.ld + col8) = pk[mi][ni][gp];
+                    }
+            }
+        } else {
+            GN_WAIT_KTILE0()
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t row = (int64_t)tm * T + (TRA ? (mi >> 1) * 128 + 16 * (2 * wr + (mi & 1)) + (r & 15) + 64 * (r >> 4)
+                                                           : wr * 128 + (mi >> 1) * 64 + (mi & 1) * 32 + r);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = tn * T + (TRB ? ni * 128 + 16 * wc + 8 * (g & 1) + 4 * hh + 64 * (g >> 1) : wc * 64 + ni * 32 + 8 * g + 4 * hh);
+                        if (row < ep.rows && col < ep.cols)                                            // cols % 4 == 0
+                            *reinterpret_cast<float4*>(outp + row * ep.ld + col) =
+                                make_float4(fin(acc[mi][ni][4 * g]), fin(acc[mi][ni][4 * g + 1]), fin(acc[mi][ni][4 * g + 2]), fin(acc[mi][ni][4 * g + 3]));
+                    }
+            }
+        }
+        GN_STAMP(5)
+        break;
+    }
     const int r4 = r & ~3;
     if constexpr (ROLE == 0 || ROLE == 1 || ROLE == 4) {
         // bf16 result (a conv output on its way to the max-pool, or the gradient wrt a BatchNorm output; both are only read
@@ -447,7 +656,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
                     }
                 }
             GN_STAMP(5)
-            return;
+            break;
         }
     }
 #pragma unroll
@@ -469,6 +678,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
             }
         }
     GN_STAMP(5)
+    } while (0);
+    if (!more) break;
+    vb = vb_next;
+  }
+#undef GN_PROLOGUE
+#undef GN_WAIT_KTILE0
+#undef GN_LOAD_BIAS
 }
 
 }  // namespace
@@ -492,8 +708,22 @@ static int launch_256_t(const char* name, const typename AL::P& ap, const typena
         attr_set = true;
     }
     GN_REQUIRE(tiles_m * tiles_n * nsplit < (1ll << 31), GOALNET_E_SHAPE, "%s: too many blocks", name);
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE, F16>), dim3((unsigned)(tiles_m * tiles_n * nsplit)), dim3(512), LDS_BYTES, st,
-                       ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps);
+    // persistent launch: one block per CU (128 KB of LDS: one fits) walks the virtual blocks; a multiple of 8 blocks keeps every
+    // virtual block on the XCD a plain launch would have given it. GOALNET_PERSISTENT=0: one block per tile (A/B runs).
+    static const int persistent_blocks = [] {
+        const char* e = getenv("GOALNET_PERSISTENT");
+        if (e && atoi(e) == 0) return 0;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return (e && atoi(e) > 1 ? atoi(e) : cus) & ~7;
+    }();
+    const int total = (int)(tiles_m * tiles_n * nsplit);
+    // Measured per role (rocprofv3, bench step): the conv forward gains 4-5 %, linear5's dX 2-4 %, the data gradient nothing;
+    // the split-K roles run few, long blocks (nothing to hide) and linear5's dW lost 3-6 %: those keep one block per tile.
+    constexpr bool walk = walks_tiles(ROLE);
+    const int grid = walk && persistent_blocks > 0 && total > persistent_blocks ? persistent_blocks : total;
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AL, BL, ROLE, F16>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st,
+                       ap, bp, ep, (int)tiles_m, (int)tiles_n, m_fast, ktiles, kps, total);
     GN_LAUNCH_CHECK(name);
     return 0;
 }
@@ -516,8 +746,8 @@ int launch_conv_bf16_256(const char* name, const __hip_bfloat16* x_pad, int H, i
     typedef ConvAPadLoader256<64> AL;
     typedef KCLoader256<32> BL;
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
-    AL::P ap{x_pad, H, W, Cin, M};
-    BL::P bp{w, (int64_t)9 * Cin, Cout, Cin};
+    AL::P ap{x_pad, H, W, Cin, M, 0, 0u};
+    BL::P bp{w, (int64_t)9 * Cin, Cout, Cin, 0, 0u};
     const int kt = 9 * Cin / BKH;
     // ROLE 0 carries the bias (in its accumulator start) and the optional ReLU; ROLE 1 stores raw accumulators
     return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_256<AL, BL, 0>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, f16, st)
@@ -561,8 +791,8 @@ int launch_linear_fwd_bf16_256(const char* name, const __hip_bfloat16* x, int64_
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (J + T - 1) / T;
     const int ktiles = (int)(K / BKH);
     const int kps = (ktiles + nsplit - 1) / nsplit;
-    AL::P ap{x, ldx, M, 0};
-    BL::P bp{w, K, J, 0};
+    AL::P ap{x, ldx, M, 0, 0, 0u};
+    BL::P bp{w, K, J, 0, 0, 0u};
     EpiP ep{EPI_RAW, slabs, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
     return launch_256<AL, BL, 3>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, f16, st);
 }
@@ -573,8 +803,8 @@ int launch_linear_dx_bf16_256(const char* name, const __hip_bfloat16* dy, int64_
     typedef KCLoader256<64> AL;
     typedef MCLoader256 BL;
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (K + T - 1) / T;
-    AL::P ap{dy, lddy, M, 0};
-    BL::P bp{w, K, (int)K, J};
+    AL::P ap{dy, lddy, M, 0, 0, 0u};
+    BL::P bp{w, K, (int)K, J, 0, 0, 0u};
     EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0, dx16};
     return launch_256<AL, BL, 4>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, J / BKH, J / BKH, f16, st);
 }
@@ -587,8 +817,8 @@ int launch_linear_dw_bf16_256(const char* name, const __hip_bfloat16* dy, int64_
     typedef MCLoader256 BL;
     const int64_t tiles_m = (J + T - 1) / T, tiles_n = (K + T - 1) / T;
     const int ktiles = (M + BKH - 1) / BKH;
-    AL::P ap{dy, lddy, J, M};
-    BL::P bp{x, ldx, (int)K, M};
+    AL::P ap{dy, lddy, J, M, 0, 0, 0u};
+    BL::P bp{x, ldx, (int)K, M, 0, 0, 0u};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
     return launch_256<AL, BL, 5>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, f16, st);
 }
@@ -602,10 +832,52 @@ int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const _
     const int ktiles = (int)((Mp + BKH - 1) / BKH);
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
-    AL::P ap{dy_pad, Cout, Cout, Mp};
-    BL::P bp{x_pad, Wp2, Cin, Mp};
+    AL::P ap{dy_pad, Cout, Cout, Mp, 0, 0, 0u};
+    BL::P bp{x_pad, Wp2, Cin, Mp, Cin, 0, 0u};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
     return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, f16, st);
+}
+
+// ---- split operands (bf16x6): the same kernels over 6 K-segments of [hi | mid | lo] operands (comment at SEGMAP_A) ------------
+// conv 3x3 forward / data gradient: x_pad3 = zero-padded [pixels][3 Cin], w3 = [Cout][9][3 Cin]; fp32 result
+int launch_conv_x6_256(const char* name, const __hip_bfloat16* x_pad3, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w3,
+                       int Cout, const EpiP& ep, hipStream_t st) {
+    typedef ConvAPadLoader256<64, true> AL;
+    typedef KCLoader256<32, true> BL;
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
+    AL::P ap{x_pad3, H, W, 3 * Cin, M, Cin, SEGMAP_A};
+    BL::P bp{w3, (int64_t)9 * 3 * Cin, Cout, 3 * Cin, Cin, SEGMAP_B};
+    const int kt = 9 * 6 * Cin / BKH;
+    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_256<AL, BL, 0>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, false, st)
+                                                            : launch_256<AL, BL, 1>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, false, st);
+}
+
+int wgrad_x6_splits_256(int64_t Mp, int Cin, int Cout) {
+    const int64_t tiles = (int64_t)((Cout + T - 1) / T) * ((9 * Cin + T - 1) / T);
+    const int ktiles = 6 * (int)((Mp + BKH - 1) / BKH);
+    int64_t s = (2048 + tiles - 1) / tiles;
+    const int64_t smax = ktiles / 64 > 1 ? ktiles / 64 : 1;
+    if (s > smax) s = smax;
+    for (int64_t c = s; c < s + 32 && c <= smax; ++c)
+        if ((tiles * c) % 256 == 0) { s = c; break; }
+    if (s > 1024) s = 1024;
+    const int kps = (int)((ktiles + s - 1) / s);
+    return (ktiles + kps - 1) / kps;
+}
+
+// conv 3x3 weight gradient: dy_pad3 = [padded pixels][3 Cout], x_pad3 = [padded pixels][3 Cin]; slabs[split][Cout][9 Cin]
+int launch_wgrad_x6_256(const char* name, const __hip_bfloat16* x_pad3, const __hip_bfloat16* dy_pad3, int Wp2, int Cin, int Cout,
+                        int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
+    typedef MCLoader256T<true> AL;
+    typedef ConvWgradBLoader256T<true> BL;
+    const int64_t tiles_m = (Cout + T - 1) / T, tiles_n = (9 * Cin + T - 1) / T;
+    const int seg_kt = (int)((Mp + BKH - 1) / BKH), ktiles = 6 * seg_kt;
+    GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
+    const int kps = (ktiles + nsplit - 1) / nsplit;
+    AL::P ap{dy_pad3, (int64_t)3 * Cout, Cout, Mp, seg_kt, Cout, SEGMAP_A};
+    BL::P bp{x_pad3, Wp2, Cin, Mp, 3 * Cin, seg_kt, SEGMAP_B};
+    EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
+    return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, false, st);
 }
 
 }  // namespace goalnet

@@ -413,6 +413,43 @@ def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
     return dw
 
 
+# ---- precision = "bf16x6" (csrc/split3.hip): fp32 operands as [hi | mid | lo] bf16 triples, six partial products per product ----
+def split3_padded(x, scale, shift, ypad3, N, H, W, C):
+    """x fp32 (N,H,W,C) [* scale + shift per channel] -> interior of the zero-padded (N,H+2,W+2,3C) bf16 view `ypad3`"""
+    _chk(x, scale, shift, ypad3)
+    _req(x.dtype == F32 and ypad3.dtype == torch.bfloat16 and x.numel() == N * H * W * C and ypad3.numel() >= N * (H + 2) * (W + 2) * 3 * C,
+         "split3_padded: x fp32 (N,H,W,C), ypad3 bf16 (N,H+2,W+2,3C)")
+    check(lib().goalnet_split3_padded(x.data_ptr(), _p(scale), _p(shift), ypad3.data_ptr(), N, H, W, C, _s()), "split3_padded")
+    return ypad3
+
+
+def split3_rows(x, y3, rows, C):
+    """x fp32 [rows][C] -> y3 bf16 [rows][3C]"""
+    _chk(x, y3)
+    _req(x.dtype == F32 and y3.dtype == torch.bfloat16 and x.numel() == rows * C and y3.numel() == 3 * rows * C, "split3_rows: sizes / dtypes")
+    check(lib().goalnet_split3_rows(x.data_ptr(), y3.data_ptr(), rows, C, _s()), "split3_rows")
+    return y3
+
+
+def conv3x3_fwd_x6(xpad3, w3, bias, relu, y, N, H, W, Cin, Cout):
+    _chk(xpad3, w3, bias, y)
+    _req(xpad3.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and y.dtype == F32 and w3.numel() == Cout * 27 * Cin
+         and y.numel() == N * H * W * Cout and xpad3.numel() >= N * (H + 2) * (W + 2) * 3 * Cin, "conv3x3_fwd_x6: sizes / dtypes")
+    check(lib().goalnet_conv3x3_fwd_x6(xpad3.data_ptr(), w3.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()), "conv3x3_fwd_x6")
+    return y
+
+
+def conv3x3_wgrad_x6(xpad3, dypad3, dw, N, H, W, Cin, Cout):
+    _chk(xpad3, dypad3, dw)
+    _req(xpad3.dtype == torch.bfloat16 and dypad3.dtype == torch.bfloat16 and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin,
+         "conv3x3_wgrad_x6: sizes / dtypes")
+    nbytes = lib().goalnet_conv3x3_wgrad_x6_ws_bytes(N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
+    check(lib().goalnet_conv3x3_wgrad_x6(xpad3.data_ptr(), dypad3.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, N, H, W, Cin, Cout, _s()),
+          "conv3x3_wgrad_x6")
+    return dw
+
+
 def linear_bwd_dx_bf16(dy, w, dx, mult=None):
     _chk(dy, w, dx, mult)
     _req(dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32, "linear_bwd_dx_bf16: argument check failed: dy.dtype in H16 and w.dtype == dy.dtype and dx.dtype == F32")

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GOALNET_ABI_VERSION 2
+#define GOALNET_ABI_VERSION 3
 
 #define GOALNET_OK 0
 #define GOALNET_E_NULL (-1)      /* required pointer is NULL */
@@ -206,6 +206,22 @@ int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const f
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
                                int N, int H, int W, int Cin, int Cout, int f16, void* stream);
+/* ---- precision = "bf16x6" (csrc/split3.hip): the 3 x 3 convolutions of VisBl blocks 2 and 3 (/root/reference/utils.py:156-164,
+ * 179-187; their backward, /root/reference/main.py:192) with fp32-grade products on the 16-bit MFMA. An fp32 operand value is
+ * stored as three bf16 values hi + mid + lo (exact), [hi | mid | lo] along the channel axis; a convolution is ONE launch of the
+ * 16-bit kernel over the six largest partial products as six K-segments, fp32 accumulation, fp32 result.
+ *   split3_padded : x fp32 [N][H][W][C] (optional per-channel affine = the BatchNorm, applied in fp32) -> zero-padded
+ *                   [N][H+2][W+2][3 C] bf16, interior only (borders / guards zeroed once by the caller, layout of to_bf16_padded)
+ *   split3_rows   : x fp32 [rows][C] -> [rows][3 C] bf16 (weights [Cout][9][Cin] -> [Cout][9][3 Cin])
+ *   conv3x3_fwd_x6: y fp32 = act(conv(x, w) + bias); the data gradient = the same call on the split gradient and flipped weights
+ *   conv3x3_wgrad_x6: dw fp32 [Cout][3][3][Cin] from split x and split dy (padded layouts) */
+int goalnet_split3_padded(const float* x, const float* scale, const float* shift, void* y_pad3, int N, int H, int W, int C, void* stream);
+int goalnet_split3_rows(const float* x, void* y3, int64_t rows, int C, void* stream);
+int goalnet_conv3x3_fwd_x6(const void* x_pad3, const void* w3, const float* bias, int relu, float* y,
+                           int N, int H, int W, int Cin, int Cout, void* stream);
+size_t goalnet_conv3x3_wgrad_x6_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int goalnet_conv3x3_wgrad_x6(const void* x_pad3, const void* dy_pad3, float* dw, void* ws, size_t ws_bytes,
+                             int N, int H, int W, int Cin, int Cout, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
                                float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream);
 /* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */

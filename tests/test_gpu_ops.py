@@ -754,3 +754,23 @@ def test_bf16_pooled_activation_variants_match_the_fp32_kernels_on_the_stored_va
             out[name] = (red.clone(), coef3, dy, buf.clone(), dparts)
         for u, v in zip(out["f32"], out["b16"]):
             assert torch.equal(u, v)
+
+
+def test_tile_walk_of_the_256_kernel_equals_one_block_per_tile_bit_for_bit():
+    """The 16-bit conv forward / data gradient / linear5 dX launch ONE block per CU that walks the tiles (next tile's operands
+    staged under the current epilogue); GOALNET_PERSISTENT=0 launches one block per tile. Same tiles, same K order: every output
+    of scripts/probe/swap_hash.py (all six roles of gemm_bf16_256.hip, bf16 and fp16, whole and ragged shapes, 16-bit and fp32
+    results) must hash identically. The switch is read once per process, hence two child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for persistent in ("1", "0"):
+        env = dict(os.environ, GOALNET_PERSISTENT=persistent)
+        env.pop("GOALNET_LIB_PATH", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "probe", "swap_hash.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0].count("\n") >= 24, outs[0]
+    assert outs[0] == outs[1]
