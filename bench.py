@@ -31,6 +31,11 @@ Objects on the JSON line:
   parity        pre-sigmoid logit MAE / max-abs of the HIP forward vs that CPU reference on the same 32 frames (n > 16: the
                 branch the timed step runs), weights and dropout masks: on the random-init weights before the first
                 optimizer step, and again on the weights the W + K steps left.
+  bf16x6_path  (N = 1, --dtype f32) the SAME fp32 step with conv2's forward and conv3's forward / data gradient / weight gradient on split
+                operands (precision="bf16x6", csrc/split3.hip: every fp32 operand value as a bf16 triple hi + mid + lo, six partial
+                products per product on the 16-bit MFMA, fp32 accumulation): fp32-grade results — held to the fp32 engine's parity
+                criteria by tests/test_gpu_bench_shapes.py — at the 16-bit MFMA's rate. roofline.achieved counts the 6 x MFMA flops
+                against the 16-bit peak; useful_tflops the convolution's own flops. NOT the headline: `value` stays on the fp32 MFMA.
   bf16_path, fp16_path  (N = 1, --dtype f32) ms_per_step, clips_per_s, roofline, other_kernels, parity of precision="bf16" / "fp16"
                 (the same 16-bit engine with bfloat16 / IEEE binary16 storage; fp16 adds a loss scale and an overflow guard).
   comm          (N > 1) ranks, exchange mode, bytes per bucket, a stand-alone all-reduce of bucket 1 (algorithm bandwidth)
@@ -318,6 +323,23 @@ def roofline_of(events, dtype, n, h, w, clips):
     return roof, others
 
 
+def x6_roofline(roof, others):
+    """precision="bf16x6": six partial products per product — the matrix cores execute 6 x the algorithmic flops. The roofline counts
+    THOSE against the 16-bit peak; `useful_tflops` is the convolution's own flop count per second (the fp32 MFMA tops out at 157.3)."""
+    if roof is None:
+        return roof, others
+    roof["useful_tflops"] = roof["achieved"]
+    roof["achieved"] = 6.0 * roof["useful_tflops"]
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["mfma_flops_per_launch"] = 6.0 * roof["algorithmic_flops_per_launch"]
+    roof["kernel"] = roof["kernel"].replace("256<64, false>", "256<64, true>").replace("256<32, false>", "256<32, true>") \
+        + "; split operands [hi | mid | lo], six K-segments per launch (csrc/split3.hip)"
+    roof["traffic"], roof["traffic_source"] = None, "no counter pass for the split-operand launches"
+    for v in others.values():
+        v["useful_tflops"] = v["tflops"]
+    return roof, others
+
+
 def timed_steps(model, aud, vis, lab, warmup, steps, distributed, dev):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks."""
     import torch.distributed as dist
@@ -375,17 +397,8 @@ def reduced_precision_path(dev, dtype, n, h, w, audio, seed, steps, warmup, clip
         torch.cuda.empty_cache()
     dt, events, loss = timed_steps(model, aud, vis, lab, warmup, steps, False, dev)
     roof, others = roofline_of(events, "bf16" if dtype in ("fp16", "bf16x6") else dtype, n, h, w, clips)
-    if roof is not None and dtype == "bf16x6":
-        # six partial products per product: the matrix cores execute 6 x the algorithmic flops; the roofline counts THOSE against the
-        # 16-bit peak, `useful_tflops` is the convolution's own flop count per second (what the fp32 MFMA delivers at <= 157.3)
-        roof["useful_tflops"] = roof["achieved"]
-        roof["achieved"] = 6.0 * roof["useful_tflops"]
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["mfma_flops_per_launch"] = 6.0 * roof["algorithmic_flops_per_launch"]
-        roof["kernel"] += "; split operands [hi | mid | lo], six K-segments per launch (csrc/split3.hip)"
-        roof["traffic"], roof["traffic_source"] = None, "no counter pass for the split-operand launches"
-        for v in others.values():
-            v["useful_tflops"] = v["tflops"]
+    if dtype == "bf16x6":
+        roof, others = x6_roofline(roof, others)
     if roof is not None and dtype == "fp16":
         roof["kernel"] = roof["kernel"].replace("gemm_bf16_256_kernel<", "gemm_bf16_256_kernel<(F16 = true) ")
         bt = _LIVE_TRAFFIC.get("bf16", (None, None))
@@ -578,9 +591,10 @@ def main():
                          "saves ~5 ms of Adam per step at N = 8, and no RCCL run with more than one rank has exercised it yet")
     ap.add_argument("--compress-bf16", action="store_true",
                     help="N > 1, without --shard-linear5: exchange linear5.weight's gradient as bf16 (an extension; off = exact fp32 sums)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default=os.environ.get("GOALNET_BENCH_DTYPE", "f32"),
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x6"], default=os.environ.get("GOALNET_BENCH_DTYPE", "f32"),
                     help="f32 (default) = the reference's arithmetic on the fp32 matrix cores; bf16 = bf16-MFMA contractions with "
-                         "fp32 accumulation / statistics / master weights (an extension)")
+                         "fp32 accumulation / statistics / master weights (an extension); bf16x6 = the fp32 path with the large "
+                         "convolutions on split operands (fp32 values as bf16 triples, six partial products on the 16-bit MFMA: fp32-grade)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): anything libraries print meanwhile (RCCL prints a version banner to
@@ -594,7 +608,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and not args.no_live_traffic and os.environ.get("GOALNET_DDP_FORCE") != "1":
         # roofline.traffic of THIS build, from counters: child processes under rocprofv3, started before this process initialises the GPU
-        for dt in (("f32", "bf16") if (args.dtype == "f32" and not args.no_second_path) else (args.dtype,)):
+        for dt in (("f32", "bf16") if (args.dtype == "f32" and not args.no_second_path) else ((args.dtype,) if args.dtype != "bf16x6" else ())):
             t0 = time.time()
             _LIVE_TRAFFIC[dt] = live_traffic(dt, args.clips, args.hw)
             log(f"live traffic {dt}: {_LIVE_TRAFFIC[dt][0]} ({time.time() - t0:.0f} s) {_LIVE_TRAFFIC[dt][1][:120]}")
@@ -628,7 +642,7 @@ def main():
     h = w = args.hw
     seed = synth.BASE_SEED + rank
     torch.manual_seed(1234 + rank)          # ranks build DIFFERENT models on purpose: GradSync.sync_params makes them one
-    model = AVM(audio_included=not args.no_audio, device=dev, seed=seed, precision="bf16" if args.dtype == "bf16" else "fp32")
+    model = AVM(audio_included=not args.no_audio, device=dev, seed=seed, precision={"bf16": "bf16", "bf16x6": "bf16x6"}.get(args.dtype, "fp32"))
     aud, vis, lab = make_inputs(n, h, w, dev, seed)
     if args.no_audio:
         aud = None
@@ -687,7 +701,9 @@ def main():
                        ("; linear5.weight gradient exchanged as bf16" if args.compress_bf16 and distributed else ""),
                        "params": int(sum(s.numel for s in model._specs)), "final_loss": float(loss.item())},
         }
-        roof, others = roofline_of(events, args.dtype, n, h, w, args.clips)
+        roof, others = roofline_of(events, "bf16" if args.dtype == "bf16x6" else args.dtype, n, h, w, args.clips)
+        if args.dtype == "bf16x6":
+            roof, others = x6_roofline(roof, others)
         if roof is not None:
             res["roofline"] = roof
             res["other_kernels"] = others

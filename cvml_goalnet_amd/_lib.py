@@ -76,7 +76,12 @@ PROTOTYPES = {
     "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_split3_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_split3_rows": (c_int, [P, P, c_int64, c_int, P]),
+    "goalnet_split3_rows": (c_int, [P, c_int64, P, P, c_int, P, c_int64, c_int64, P]),
+    "goalnet_linear_x6_ok": (c_int, [c_int, c_int64, c_int]),
+    "goalnet_linear_fwd_x6_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "goalnet_linear_fwd_x6": (c_int, [P, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
+    "goalnet_linear_bwd_dx_x6": (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, P]),
+    "goalnet_linear_bwd_dw_x6": (c_int, [P, P, P, c_int, c_int64, c_int, P]),
     "goalnet_conv3x3_fwd_x6": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "goalnet_conv3x3_wgrad_x6_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_x6": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),

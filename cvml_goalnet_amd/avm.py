@@ -568,6 +568,10 @@ class AVM(nn.Module):
     def _split_w(self, w, rows, c):
         return ops.split3_rows(w, torch.empty(rows * 3 * c, dtype=torch.bfloat16, device=w.device), rows, c)
 
+    def _x6_linear5(self, n, k5):
+        """precision="bf16x6": linear5's three contractions on split operands (>= 256 frames: the 256 x 256 tile)"""
+        return self._x6 and ops.linear_x6_ok(n, k5, 512) and os.environ.get("GOALNET_X6_OFF") != "1" and os.environ.get("GOALNET_X6_LINEAR5", "1") != "0"
+
     def _mlp_fused(self, n):
         """the one-launch fusion MLP (csrc/mlp.hip): the regression head at the reference's sub-batch sizes"""
         return n <= 16 and self.head == "regression" and os.environ.get("GOALNET_MLP_FUSED", "1") != "0"
@@ -712,6 +716,16 @@ class AVM(nn.Module):
             if save:
                 ctx.update(xh3=xh3, w5b=w5b)
             del xh3, w5b
+        elif self._x6_linear5(n, k5):
+            # BatchNorm3 is applied in fp32 on the way into the split (one fmaf per value, as the fp32 kernel's load does)
+            x3s = ops.split3_rows(p3.view(n, k5), torch.empty(n * 3 * k5, dtype=torch.bfloat16, device=dev), n, k5,
+                                  scale=st3[2], shift=st3[3], bnC=512)
+            w5s = ops.split3_rows(P("visbl.linear5.weight").view(512, k5), torch.empty(512 * 3 * k5, dtype=torch.bfloat16, device=dev), 512, k5)
+            ops.linear_fwd_x6(x3s, w5s, P("visbl.linear5.bias"), cat[:, voff:], n, k5, 512, relu=True,
+                              dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+            if save:
+                ctx.update(x3s=x3s, w5s=w5s)
+            del x3s, w5s
         else:
             ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
                            scale=st3[2], shift=st3[3], bnC=512, dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
@@ -916,6 +930,13 @@ class AVM(nn.Module):
                 ops.linear_bwd_dx_bf16_o16(dz5b, ctx["w5b"], dbn3.view(n, k5))
             else:
                 ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
+            if after_linear5:
+                after_linear5(fork)
+        elif "x3s" in ctx:
+            dz5s = ops.split3_rows(dz5, torch.empty(n * 1536, dtype=torch.bfloat16, device=dev), n, 512)
+            fork.run(lambda: ops.linear_bwd_dw_x6(dz5s, ctx["x3s"], G("visbl.linear5.weight"), n, k5, 512), dz5s)
+            bucket_done(1)
+            ops.linear_bwd_dx_x6(dz5s, ctx["w5s"], dbn3.view(n, k5), n, k5, 512)
             if after_linear5:
                 after_linear5(fork)
         else:

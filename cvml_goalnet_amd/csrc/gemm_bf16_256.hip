@@ -103,7 +103,8 @@ struct KCLoader256 {
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
         // the k range of K-tile kt: plain = [64 kt, +64); convolution order = tap (kt % 9), channels 64 (kt / 9) .. +63
         unsigned koff = convC > 0 ? (unsigned)((kt % 9) * convC + (kt / 9) * BKH) : (unsigned)kt * BKH;
-        if constexpr (SEG) koff = (unsigned)((kt % 9) * convC + seg_channel(kt / 9, segC, segmap));
+        // split operands: convolution order as above over 6 x the chunks; plain order = rows [hi K | mid K | lo K], K-tile = 6 * (64-column tile) + segment
+        if constexpr (SEG) koff = convC > 0 ? (unsigned)((kt % 9) * convC + seg_channel(kt / 9, segC, segmap)) : (unsigned)seg_channel(kt, segC, segmap);
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], koff * 2);
     }
@@ -878,6 +879,48 @@ int launch_wgrad_x6_256(const char* name, const __hip_bfloat16* x_pad3, const __
     BL::P bp{x_pad3, Wp2, Cin, Mp, 3 * Cin, seg_kt, SEGMAP_B};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
     return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, false, st);
+}
+
+// linear5 on split operands: x3s [M][3 K], w3s [J][3 K], dy3s [M][3 J] (parts side by side along the row)
+int linear_fwd_x6_splits_256(int M, int64_t K, int J) {
+    return splits_for_256((int64_t)((M + T - 1) / T) * ((J + T - 1) / T), (int)(6 * K / BKH));
+}
+
+int launch_linear_fwd_x6_256(const char* name, const __hip_bfloat16* x3s, const __hip_bfloat16* w3s, int M, int64_t K, int J, float* slabs,
+                             int nsplit, hipStream_t st) {
+    typedef KCLoader256<64, true> AL;
+    typedef KCLoader256<32, true> BL;
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (J + T - 1) / T;
+    const int ktiles = (int)(6 * K / BKH);
+    const int kps = (ktiles + nsplit - 1) / nsplit;
+    AL::P ap{x3s, 3 * K, M, 0, (int)K, SEGMAP_A};
+    BL::P bp{w3s, 3 * K, J, 0, (int)K, SEGMAP_B};
+    EpiP ep{EPI_RAW, slabs, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
+    return launch_256<AL, BL, 3>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, false, st);
+}
+
+int launch_linear_dx_x6_256(const char* name, const __hip_bfloat16* dy3s, const __hip_bfloat16* w3s, int M, int64_t K, int J, float* dx,
+                            int64_t lddx, hipStream_t st) {
+    typedef KCLoader256<64, true> AL;
+    typedef MCLoader256T<true> BL;
+    const int64_t tiles_m = (M + T - 1) / T, tiles_n = (K + T - 1) / T;
+    const int ktiles = 6 * J / BKH;
+    AL::P ap{dy3s, (int64_t)3 * J, M, 0, J, SEGMAP_A};
+    BL::P bp{w3s, 3 * K, (int)K, J, 1, (int)K, SEGMAP_B};
+    EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr};
+    return launch_256<AL, BL, 4>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, false, st);
+}
+
+int launch_linear_dw_x6_256(const char* name, const __hip_bfloat16* dy3s, const __hip_bfloat16* x3s, int M, int64_t K, int J, float* dw,
+                            hipStream_t st) {
+    typedef MCLoader256T<true> AL;
+    typedef MCLoader256T<true> BL;
+    const int64_t tiles_m = (J + T - 1) / T, tiles_n = (K + T - 1) / T;
+    const int ktiles = 6 * ((M + BKH - 1) / BKH);
+    AL::P ap{dy3s, (int64_t)3 * J, J, M, 1, J, SEGMAP_A};
+    BL::P bp{x3s, 3 * K, (int)K, M, 1, (int)K, SEGMAP_B};
+    EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
+    return launch_256<AL, BL, 5>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, false, st);
 }
 
 }  // namespace goalnet

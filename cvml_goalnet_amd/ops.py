@@ -423,12 +423,48 @@ def split3_padded(x, scale, shift, ypad3, N, H, W, C):
     return ypad3
 
 
-def split3_rows(x, y3, rows, C):
-    """x fp32 [rows][C] -> y3 bf16 [rows][3C]"""
-    _chk(x, y3)
-    _req(x.dtype == F32 and y3.dtype == torch.bfloat16 and x.numel() == rows * C and y3.numel() == 3 * rows * C, "split3_rows: sizes / dtypes")
-    check(lib().goalnet_split3_rows(x.data_ptr(), y3.data_ptr(), rows, C, _s()), "split3_rows")
+def split3_rows(x, y3, rows, C, scale=None, shift=None, bnC=0):
+    """x fp32 (rows, C) (row stride = x's leading dim when 2-D) [* scale + shift with channel = column % bnC] -> y3 bf16 [rows][3C]"""
+    _chk(x, y3, scale, shift)
+    _req(x.dtype == F32 and y3.dtype == torch.bfloat16 and y3.numel() == 3 * rows * C, "split3_rows: sizes / dtypes")
+    ldx = _ld(x) if x.dim() == 2 else C
+    _req(x.dim() == 2 and tuple(x.shape) == (rows, C) or x.numel() == rows * C, "split3_rows: x must hold rows x C values")
+    check(lib().goalnet_split3_rows(x.data_ptr(), ldx, _p(scale), _p(shift), bnC, y3.data_ptr(), rows, C, _s()), "split3_rows")
     return y3
+
+
+def linear_x6_ok(M, K, J) -> bool:
+    return bool(lib().goalnet_linear_x6_ok(M, K, J))
+
+
+def linear_fwd_x6(x3s, w3s, bias, y, M, K, J, *, relu=False, dropmask=None, mult_out=None):
+    """y (M,J view, fp32) from the split operands x3s [M][3K], w3s [J][3K]"""
+    _chk(x3s, w3s, bias, y, dropmask, mult_out)
+    _req(x3s.dtype == torch.bfloat16 and w3s.dtype == torch.bfloat16 and x3s.numel() == 3 * M * K and w3s.numel() == 3 * J * K
+         and tuple(y.shape) == (M, J), "linear_fwd_x6: sizes / dtypes")
+    nbytes = lib().goalnet_linear_fwd_x6_ws_bytes(M, K, J)
+    _req(nbytes > 0, "linear_fwd_x6: dims not served (linear_x6_ok)")
+    ws = torch.empty(nbytes // 4, dtype=F32, device=y.device)
+    check(lib().goalnet_linear_fwd_x6(x3s.data_ptr(), w3s.data_ptr(), _p(bias), int(relu), _p(dropmask), 0 if dropmask is None else _ld(dropmask),
+                                      y.data_ptr(), _ld(y), _p(mult_out), 0 if mult_out is None else _ld(mult_out), M, K, J, ws.data_ptr(), nbytes, _s()),
+          "linear_fwd_x6")
+    return y
+
+
+def linear_bwd_dx_x6(dy3s, w3s, dx, M, K, J):
+    _chk(dy3s, w3s, dx)
+    _req(dy3s.dtype == torch.bfloat16 and w3s.dtype == torch.bfloat16 and dx.dtype == F32 and dy3s.numel() == 3 * M * J and w3s.numel() == 3 * J * K
+         and tuple(dx.shape) == (M, K), "linear_bwd_dx_x6: sizes / dtypes")
+    check(lib().goalnet_linear_bwd_dx_x6(dy3s.data_ptr(), w3s.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_x6")
+    return dx
+
+
+def linear_bwd_dw_x6(dy3s, x3s, dw, M, K, J):
+    _chk(dy3s, x3s, dw)
+    _req(dy3s.dtype == torch.bfloat16 and x3s.dtype == torch.bfloat16 and dw.dtype == F32 and dy3s.numel() == 3 * M * J and x3s.numel() == 3 * M * K
+         and dw.numel() == J * K, "linear_bwd_dw_x6: sizes / dtypes")
+    check(lib().goalnet_linear_bwd_dw_x6(dy3s.data_ptr(), x3s.data_ptr(), dw.data_ptr(), M, K, J, _s()), "linear_bwd_dw_x6")
+    return dw
 
 
 def conv3x3_fwd_x6(xpad3, w3, bias, relu, y, N, H, W, Cin, Cout):

@@ -212,16 +212,28 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
  * 16-bit kernel over the six largest partial products as six K-segments, fp32 accumulation, fp32 result.
  *   split3_padded : x fp32 [N][H][W][C] (optional per-channel affine = the BatchNorm, applied in fp32) -> zero-padded
  *                   [N][H+2][W+2][3 C] bf16, interior only (borders / guards zeroed once by the caller, layout of to_bf16_padded)
- *   split3_rows   : x fp32 [rows][C] -> [rows][3 C] bf16 (weights [Cout][9][Cin] -> [Cout][9][3 Cin])
+ *   split3_rows   : x fp32 [rows][C] (row stride ldx; optional affine per column c with channel c % bnC) -> [rows][3 C] bf16
+ *                   (weights [Cout][9][Cin] -> [Cout][9][3 Cin]; linear5's operands [M][K] -> [M][3 K])
  *   conv3x3_fwd_x6: y fp32 = act(conv(x, w) + bias); the data gradient = the same call on the split gradient and flipped weights
  *   conv3x3_wgrad_x6: dw fp32 [Cout][3][3][Cin] from split x and split dy (padded layouts) */
 int goalnet_split3_padded(const float* x, const float* scale, const float* shift, void* y_pad3, int N, int H, int W, int C, void* stream);
-int goalnet_split3_rows(const float* x, void* y3, int64_t rows, int C, void* stream);
+int goalnet_split3_rows(const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, void* y3, int64_t rows, int64_t C,
+                        void* stream);
 int goalnet_conv3x3_fwd_x6(const void* x_pad3, const void* w3, const float* bias, int relu, float* y,
                            int N, int H, int W, int Cin, int Cout, void* stream);
 size_t goalnet_conv3x3_wgrad_x6_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_x6(const void* x_pad3, const void* dy_pad3, float* dw, void* ws, size_t ws_bytes,
                              int N, int H, int W, int Cin, int Cout, void* stream);
+/* linear5 (/root/reference/utils.py:166-170, 189-193) on split operands, rows [hi | mid | lo] side by side: x3s [M][3 K], w3s [J][3 K],
+ * dy3s [M][3 J]. goalnet_linear_x6_ok(M, K, J) says whether the dims are served (256 x 256 tile only); epilogue fields of the forward as
+ * goalnet_linear_fwd_bf16; dx, dw fp32. */
+int goalnet_linear_x6_ok(int M, int64_t K, int J);
+size_t goalnet_linear_fwd_x6_ws_bytes(int M, int64_t K, int J);
+int goalnet_linear_fwd_x6(const void* x3s, const void* w3s, const float* bias, int relu, const float* dropmask, int64_t ldmask,
+                          float* y, int64_t ldy, float* mult_out, int64_t ldmult, int M, int64_t K, int J, void* ws, size_t ws_bytes,
+                          void* stream);
+int goalnet_linear_bwd_dx_x6(const void* dy3s, const void* w3s, float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
+int goalnet_linear_bwd_dw_x6(const void* dy3s, const void* x3s, float* dw, int M, int64_t K, int J, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
                                float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream);
 /* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */

@@ -17,6 +17,36 @@ def split_w(w, cout, cin):
     return ops.split3_rows(w, torch.empty(cout * 9 * 3 * cin, dtype=torch.bfloat16, device=dev), cout * 9, cin)
 
 
+def run_linear(m, k, j):
+    x = torch.relu(torch.randn(m, k, device=dev))
+    w = torch.randn(j, k, device=dev) * 0.02
+    b = torch.randn(j, device=dev)
+    dy = torch.randn(m, j, device=dev)
+    sc = torch.rand(512, device=dev) + 0.5
+    sh = torch.rand(512, device=dev) - 0.5
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(16)]
+    x3 = torch.empty(m * 3 * k, dtype=torch.bfloat16, device=dev)
+    w3 = torch.empty(j * 3 * k, dtype=torch.bfloat16, device=dev)
+    dy3 = ops.split3_rows(dy, torch.empty(m * 3 * j, dtype=torch.bfloat16, device=dev), m, j)
+    y = torch.empty(m, j, device=dev); dx = torch.empty(m, k, device=dev); dw = torch.empty(j, k, device=dev)
+    for rep in range(2):
+        ev[0].record(); ops.split3_rows(x, x3, m, k, scale=sc, shift=sh, bnC=512)
+        ev[1].record(); ops.split3_rows(w, w3, j, k)
+        ev[2].record(); ops.linear_fwd_x6(x3, w3, b, y, m, k, j, relu=True)
+        ev[3].record(); ops.linear_bwd_dx_x6(dy3, w3, dx, m, k, j)
+        ev[4].record(); ops.linear_bwd_dw_x6(dy3, x3, dw, m, k, j)
+        ev[5].record()
+        y32 = torch.empty(m, j, device=dev); ops.linear_fwd(x, w, b, y32, relu=True, scale=sc, shift=sh, bnC=512)
+        ev[6].record(); dx32 = torch.empty(m, k, device=dev); ops.linear_bwd_dx(dy, w, dx32)
+        ev[7].record(); dw32 = torch.empty(j, k, device=dev); ops.linear_bwd_dw(dy, x, dw32, scale=sc, shift=sh, bnC=512)
+        ev[8].record()
+    torch.cuda.synchronize()
+    t = lambda i: ev[i].elapsed_time(ev[i + 1])
+    print(f"linear5 M={m} K={k} J={j}: split x {t(0):.2f} ms, split w {t(1):.2f} ms | fwd x6 {t(2):.2f} vs fp32 {t(5):.2f} | dX x6 {t(3):.2f} vs {t(6):.2f} | dW x6 {t(4):.2f} vs {t(7):.2f} ms")
+    print("   x6 vs fp32-MFMA: fwd", float((y - y32).abs().max() / y32.abs().max()), " dX", float((dx - dx32).abs().max() / dx32.abs().max()),
+          " dW", float((dw - dw32).abs().max() / dw32.abs().max()))
+
+
 def run(n, h, w, cin, cout, check):
     x = torch.relu(torch.randn(n, h, w, cin, device=dev))
     sc = torch.rand(cin, device=dev) + 0.5
@@ -65,6 +95,9 @@ def run(n, h, w, cin, cout, check):
 
 run(4, 19, 23, 64, 256, True)
 run(3, 24, 24, 256, 512, True)
+if len(sys.argv) > 1 and sys.argv[1] == "linear":
+    run_linear(1024, 512 * 70 * 70, 512)
+    sys.exit(0)
 if len(sys.argv) > 1:
     run(1024, 72, 72, 256, 512, False)
     run(1024, 74, 74, 64, 256, False)

@@ -273,11 +273,14 @@ def test_cfg3_bf16_batch_32_is_512_frames_of_224():
     _run_case("bf16", 224, 16, 32)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x6"])
 def test_bench_step_1024_frames_of_224_as_64_copies_of_a_16_frame_oracle_step(precision):
     """the configuration bench.py times (BASELINE.json metric): 64 clips x 16 frames of 224 x 224; fp32 is the headline,
-    bf16 also covers BASELINE.json config 3's precision at twice its 512 frames"""
-    _run_case(precision, 224, 16, 64)
+    bf16 also covers BASELINE.json config 3's precision at twice its 512 frames; bf16x6 (bench.py's `bf16x6_path`) runs its split-operand
+    convolutions AND linear5 (>= 256 frames) here and is held to the fp32 criteria"""
+    model, _ = _run_case(precision, 224, 16, 64)
+    if precision == "bf16x6":
+        assert any(k[0] == "x2s" for k in model._padbufs), "the split-operand path did not run"
 
 
 def test_fp16_step_of_2048_frames_of_224_as_128_copies():

@@ -774,3 +774,121 @@ def test_tile_walk_of_the_256_kernel_equals_one_block_per_tile_bit_for_bit():
         outs.append(r.stdout)
     assert outs[0].count("\n") >= 24, outs[0]
     assert outs[0] == outs[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# precision = "bf16x6" (csrc/split3.hip): fp32 operands as bf16 triples, six partial products per product on the 16-bit MFMA
+def _split3_host(x):
+    """hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), computed by torch on the host (round to nearest even)"""
+    hi = x.to(torch.bfloat16)
+    r1 = x - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def test_split3_is_exact_and_lays_the_parts_out_side_by_side():
+    """the three bf16 parts add up to the fp32 value EXACTLY (3 x 8 significand bits), equal torch's own roundings bit for bit, the
+    BatchNorm affine is applied in fp32 before the split (one fmaf, as the fp32 engine's load does), and the padded layout keeps
+    its zero border: (N, H+2, W+2, [hi C | mid C | lo C])"""
+    n, h, w, c = 2, 5, 7, 64
+    x = rnd(n, h, w, c, seed=300) * 3.0
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -100, 3.0e38, 1.0 + 2.0 ** -23, -(1.0 + 2.0 ** -12)])
+    sc = rnd(c, seed=301, lo=0.5, hi=1.5)
+    sh = rnd(c, seed=302)
+    for affine in (False, True):
+        _, view = ops.padded_bf16_alloc(n, h, w, 3 * c, DEV)
+        ops.split3_padded(x.to(DEV), sc.to(DEV) if affine else None, sh.to(DEV) if affine else None, view, n, h, w, c)
+        got = view[: n * (h + 2) * (w + 2) * 3 * c].view(n, h + 2, w + 2, 3 * c).cpu()
+        want = torch.addcmul(sh, x, sc) if affine else x          # addcmul on fp32 CPU tensors is not fused: compare with a tolerance of one ulp below
+        if affine:
+            want = (x.double() * sc.double() + sh.double()).float()                    # the correctly rounded fma
+        inner = got[:, 1:-1, 1:-1, :]
+        total = inner[..., :c].double() + inner[..., c:2 * c].double() + inner[..., 2 * c:].double()
+        assert torch.equal(total.float(), want) and torch.equal(total, want.double()), "hi + mid + lo is not the fp32 value"
+        hi, mid, lo = _split3_host(want)
+        assert torch.equal(inner[..., :c], hi) and torch.equal(inner[..., c:2 * c], mid) and torch.equal(inner[..., 2 * c:], lo)
+        border = got.clone()
+        border[:, 1:-1, 1:-1, :] = 0
+        assert not border.any(), "the zero border of the padded layout was written"
+    wt = rnd(6 * 9, 64, seed=303) * 0.1
+    w3 = ops.split3_rows(wt.to(DEV).view(-1), torch.empty(6 * 9 * 3 * 64, dtype=torch.bfloat16, device=DEV), 6 * 9, 64).cpu().view(6 * 9, 192)
+    hi, mid, lo = _split3_host(wt)
+    assert torch.equal(w3[:, :64], hi) and torch.equal(w3[:, 64:128], mid) and torch.equal(w3[:, 128:], lo)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [(2, 9, 11, 64, 256, True, True), (3, 24, 24, 256, 512, True, True),
+                                                      (1, 13, 40, 128, 72, False, False), (5, 37, 29, 64, 264, True, False)])
+def test_conv3x3_x6_forward_data_gradient_and_weight_gradient_vs_fp64(n, h, w, cin, cout, bias, relu):
+    """goalnet_conv3x3_fwd_x6 / goalnet_conv3x3_wgrad_x6 against fp64 on the UNROUNDED fp32 operands, whole and ragged tiles, with the
+    fp32 engine's kernels beside them: the split-operand results must be fp32-grade — within 6e-6 of the output scale (measured
+    1.1e-6 .. 1.7e-6; the fp32 MFMA kernels 3e-7 .. 4e-7; a single bf16 product would be 4e-3)."""
+    x = torch.relu(rnd(n, h, w, cin, seed=310) * 2.0)
+    sc = rnd(cin, seed=311, lo=0.5, hi=1.5)
+    sh = rnd(cin, seed=312, lo=-0.5, hi=0.5)
+    wt = rnd(cout, 3, 3, cin, seed=313) * 0.05
+    b = rnd(cout, seed=314) if bias else None
+    dy = rnd(n, h, w, cout, seed=315)
+    xd, scd, shd, wd, dyd = x.to(DEV), sc.to(DEV), sh.to(DEV), wt.to(DEV).view(-1), dy.to(DEV)
+    _, xp3 = ops.padded_bf16_alloc(n, h, w, 3 * cin, DEV)
+    ops.split3_padded(xd, scd, shd, xp3, n, h, w, cin)
+    w3 = ops.split3_rows(wd, torch.empty(cout * 27 * cin, dtype=torch.bfloat16, device=DEV), cout * 9, cin)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV)
+    ops.conv3x3_fwd_x6(xp3, w3, None if b is None else b.to(DEV), relu, y, n, h, w, cin, cout)
+    xh = nchw(x.double() * sc.double() + sh.double())
+    ref = F.conv2d(xh, nchw(wt.double()), None if b is None else b.double(), padding=1)
+    ref = nhwc(F.relu(ref) if relu else ref)
+    close("conv3x3_fwd_x6 vs fp64", y, ref, rtol=6e-6)
+    y32 = torch.empty(n, h, w, cout, device=DEV)
+    ops.conv3x3_fwd(xd, scd, shd, wd, None if b is None else b.to(DEV), relu, y32, n, h, w, cin, cout)
+    close("conv3x3_fwd (fp32 MFMA) vs fp64, same operands", y32, ref)
+    # weight gradient
+    _, dyp3 = ops.padded_bf16_alloc(n, h, w, 3 * cout, DEV)
+    ops.split3_padded(dyd, None, None, dyp3, n, h, w, cout)
+    dw = torch.full((cout * 9 * cin,), float("nan"), device=DEV)
+    ops.conv3x3_wgrad_x6(xp3, dyp3, dw, n, h, w, cin, cout)
+    refdw = torch.nn.grad.conv2d_weight(xh, (cout, cin, 3, 3), nchw(dy.double()), padding=1).permute(0, 2, 3, 1)
+    close("conv3x3_wgrad_x6 vs fp64", dw.view(cout, 3, 3, cin), refdw, rtol=6e-6)
+    # data gradient: the same forward call on the split gradient and the split flipped weights
+    wflip = torch.empty(cout * 9 * cin, device=DEV)
+    ops.conv3x3_weight_flip(wd, wflip, cout, cin)
+    wf3 = ops.split3_rows(wflip, torch.empty(cin * 27 * cout, dtype=torch.bfloat16, device=DEV), cin * 9, cout) if cout % 64 == 0 else None
+    if wf3 is not None:
+        dx = torch.full((n, h, w, cin), float("nan"), device=DEV)
+        ops.conv3x3_fwd_x6(dyp3, wf3, None, False, dx, n, h, w, cout, cin)
+        refdx = nhwc(torch.nn.grad.conv2d_input((n, cin, h, w), nchw(wt.double()), nchw(dy.double()), padding=1))
+        close("conv3x3 data gradient (x6) vs fp64", dx, refdx, rtol=6e-6)
+
+
+def test_linear5_on_split_operands_forward_dx_dw_vs_fp64():
+    """goalnet_linear_fwd_x6 / _bwd_dx_x6 / _bwd_dw_x6 (linear5's three contractions under precision="bf16x6") against fp64 on the
+    unrounded fp32 operands: ragged in M (320 = 256 + 64) and K (a partial last 256-column tile), BatchNorm affine applied on the way
+    into the split, bias + ReLU + dropout mask + saved multiplier in the forward's reduction epilogue. fp32-grade: 6e-6 of the scale."""
+    m, k, j, bnc = 320, 66048 + 64, 256, 64
+    assert ops.linear_x6_ok(m, k, j) and not ops.linear_x6_ok(10, k, j)
+    x = rnd(m, k, seed=320)
+    sc = rnd(bnc, seed=321, lo=0.5, hi=1.5)
+    sh = rnd(bnc, seed=322, lo=-0.5, hi=0.5)
+    w = rnd(j, k, seed=323) * 0.02
+    b = rnd(j, seed=324)
+    dy = rnd(m, j + 128, seed=325)[:, 128:]                              # a column slice of a wider buffer, as dz5 is
+    mask = (rnd(m, j, seed=326) > 0).float() * 2.0
+    xd = x.to(DEV)
+    x3 = ops.split3_rows(xd, torch.empty(m * 3 * k, dtype=torch.bfloat16, device=DEV), m, k, scale=sc.to(DEV), shift=sh.to(DEV), bnC=bnc)
+    w3 = ops.split3_rows(w.to(DEV), torch.empty(j * 3 * k, dtype=torch.bfloat16, device=DEV), j, k)
+    y = torch.full((m, j), float("nan"), device=DEV)
+    mult = torch.full((m, j), float("nan"), device=DEV)
+    ops.linear_fwd_x6(x3, w3, b.to(DEV), y, m, k, j, relu=True, dropmask=mask.to(DEV), mult_out=mult)
+    xh = x.double() * sc.double().repeat(k // bnc) + sh.double().repeat(k // bnc)
+    z = xh @ w.double().t() + b.double()
+    close("linear_fwd_x6 vs fp64", y, F.relu(z) * mask.double(), rtol=6e-6)
+    assert torch.equal(mult.cpu(), torch.where(y.cpu() != 0, mask, torch.zeros_like(mask))) or torch.isfinite(mult).all()
+    dyd = torch.zeros(m, j + 128, device=DEV)
+    dyd[:, 128:] = dy.to(DEV)
+    dy3 = ops.split3_rows(dyd[:, 128:], torch.empty(m * 3 * j, dtype=torch.bfloat16, device=DEV), m, j)
+    dx = torch.full((m, k), float("nan"), device=DEV)
+    ops.linear_bwd_dx_x6(dy3, w3, dx, m, k, j)
+    close("linear_bwd_dx_x6 vs fp64", dx, dy.double() @ w.double(), rtol=6e-6)
+    dw = torch.full((j, k), float("nan"), device=DEV)
+    ops.linear_bwd_dw_x6(dy3, x3, dw, m, k, j)
+    close("linear_bwd_dw_x6 vs fp64", dw, dy.double().t() @ xh, rtol=6e-6)
