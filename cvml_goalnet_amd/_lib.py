@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GOALNET_LIB_PATH") or os.path.join(_HERE, "libgoalnet_hip.so")   # override: A/B builds of the kernels
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAT_PARTS = 1024
 
 P = c_void_p  # device pointers and the stream travel as void*
@@ -75,16 +75,18 @@ PROTOTYPES = {
     "goalnet_conv3x3_fwd_bf16p": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, c_int, P]),
     "goalnet_conv3x3_wgrad_bf16_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "goalnet_conv3x3_wgrad_bf16": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_split3_padded": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "goalnet_split3_rows": (c_int, [P, c_int64, P, P, c_int, P, c_int64, c_int64, P]),
-    "goalnet_linear_x6_ok": (c_int, [c_int, c_int64, c_int]),
-    "goalnet_linear_fwd_x6_ws_bytes": (c_size_t, [c_int, c_int64, c_int]),
-    "goalnet_linear_fwd_x6": (c_int, [P, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P]),
-    "goalnet_linear_bwd_dx_x6": (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, P]),
-    "goalnet_linear_bwd_dw_x6": (c_int, [P, P, P, c_int, c_int64, c_int, P]),
-    "goalnet_conv3x3_fwd_x6": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
-    "goalnet_conv3x3_wgrad_x6_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "goalnet_conv3x3_wgrad_x6": (c_int, [P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "goalnet_absmax": (c_int, [P, c_int64, P, P, c_int, c_int64, c_int64, P, P]),
+    "goalnet_split_scales": (c_int, [P, P, P, P]),
+    "goalnet_split_padded": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "goalnet_split_rows": (c_int, [c_int, P, c_int64, P, P, c_int, P, P, c_int64, c_int64, P]),
+    "goalnet_conv3x3_fwd_split": (c_int, [c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "goalnet_conv3x3_wgrad_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "goalnet_conv3x3_wgrad_split": (c_int, [c_int, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "goalnet_linear_split_ok": (c_int, [c_int, c_int, c_int64, c_int]),
+    "goalnet_linear_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int64, c_int]),
+    "goalnet_linear_fwd_split": (c_int, [c_int, P, P, P, c_int, P, c_int64, P, c_int64, P, c_int64, c_int, c_int64, c_int, P, c_size_t, P, P]),
+    "goalnet_linear_bwd_dx_split": (c_int, [c_int, P, P, P, c_int64, c_int, c_int64, c_int, P, P]),
+    "goalnet_linear_bwd_dw_split": (c_int, [c_int, P, P, P, c_int, c_int64, c_int, P, P]),
     "goalnet_linear_bwd_dx_bf16": (c_int, [P, c_int64, P, P, c_int64, P, c_int64, c_int, c_int64, c_int, c_int, P]),
     "goalnet_linear_bwd_dx_bf16_o16_ok": (c_int, [c_int, c_int64, c_int]),
     "goalnet_linear_bwd_dx_bf16_o16": (c_int, [P, c_int64, P, P, c_int64, c_int, c_int64, c_int, c_int, P]),

@@ -137,13 +137,15 @@ class AVM(nn.Module):
             raise ValueError("num_classes must be in 2..8")
         self.head = head
         self.num_classes = num_classes if head == "classifier" else 1
-        if precision not in ("fp32", "bf16", "fp16", "bf16x6"):
-            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16x6' (fp32 operands as bf16 triples on the 16-bit "
-                             "MFMA), 'bf16' or 'fp16' (16-bit MFMA contractions)")
+        if precision not in ("fp32", "bf16", "fp16", "bf16x6", "fp16x3"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic), 'bf16x6' / 'fp16x3' (fp32 operands as bf16 triples / scaled "
+                             "fp16 pairs on the 16-bit MFMA: fp32-grade), 'bf16' or 'fp16' (16-bit MFMA contractions)")
         # "bf16x6": everything is stored and computed as under "fp32" except the large 3 x 3 convolutions (conv2 forward; conv3 forward,
         # data gradient and weight gradient at >= 65 536 output pixels), whose fp32 operands are split into bf16 triples hi + mid + lo
         # (exact) and multiplied as six partial products on the 16-bit MFMA with fp32 accumulation (csrc/split3.hip): fp32-grade
         # results (3-4 x the rounding error of the fp32 MFMA's own accumulation) at 1.4-1.65 x its speed.
+        # "fp16x3": the same GEMMs on fp16 PAIRS hi + mid of each value scaled by a per-tensor power of two (22 significand bits; the scale
+        # comes from a magnitude pass over the tensor, so no loss scale is involved) and three partial products: half the MFMA work.
         # "bf16" / "fp16": the dense contractions (conv2/conv3 forward + data / weight gradient, linear5) run on the 16-bit matrix
         # cores with fp32 accumulation; statistics, master weights, parameter gradients and Adam stay fp32.
         # fp16 keeps 11 significand bits against bf16's 8 (~8 x less rounding noise in the logits) but has 5 exponent bits:
@@ -224,12 +226,13 @@ class AVM(nn.Module):
 
     @precision.setter
     def precision(self, value: str):
-        if value not in ("fp32", "bf16", "fp16", "bf16x6"):
-            raise ValueError("precision must be 'fp32', 'bf16x6', 'bf16' or 'fp16'")
+        if value not in ("fp32", "bf16", "fp16", "bf16x6", "fp16x3"):
+            raise ValueError("precision must be 'fp32', 'bf16x6', 'fp16x3', 'bf16' or 'fp16'")
         self._precision = value
         self._half = value in ("bf16", "fp16")
-        self._x6 = value == "bf16x6"                                          # split-operand convolutions (csrc/split3.hip); fp32 storage
-        self._h16 = torch.float16 if value == "fp16" else torch.bfloat16     # the 16-bit storage format of the GEMM operands
+        self._parts = {"bf16x6": 3, "fp16x3": 2}.get(value, 0)                # split-operand GEMMs (csrc/split3.hip); fp32 storage
+        self._x6 = self._parts > 0
+        self._h16 = torch.float16 if value in ("fp16", "fp16x3") else torch.bfloat16     # the 16-bit storage format of the GEMM operands
         self._w5b, self._w5b_version = None, None                              # a copy in the other format is not reusable
         self._padbufs, self._padgen = {}, {}                                   # nor are the cached padded 16-bit operand buffers
         if not self._loss_scale_user:
@@ -565,12 +568,32 @@ class AVM(nn.Module):
         Only where the 256 x 256 tile is filled; everything else runs the fp32-MFMA kernels."""
         return self._x6 and m >= 65536 and cout >= 256 and os.environ.get("GOALNET_X6_OFF") != "1"
 
+    # split operands: every helper returns (parts tensor, magnitude word or None); `_osc(a, b)` = the epilogue scale of a GEMM of the two
+    def _amax_of(self, x2d, rows, c, scale=None, shift=None, bnC=0):
+        if self._parts != 2:
+            return None
+        return ops.absmax(x2d, torch.zeros(1, dtype=torch.int32, device=x2d.device), rows, c, scale=scale, shift=shift, bnC=bnC)
+
+    def _osc(self, amax_a, amax_b):
+        return ops.split_scales(amax_a, amax_b) if self._parts == 2 else None
+
     def _split_w(self, w, rows, c):
-        return ops.split3_rows(w, torch.empty(rows * 3 * c, dtype=torch.bfloat16, device=w.device), rows, c)
+        am = self._amax_of(w, rows, c)
+        return ops.split_rows(self._parts, w, torch.empty(rows * self._parts * c, dtype=self._h16, device=w.device), rows, c, amax=am), am
+
+    def _split_act(self, key, x, scale, shift, n, h, w, c):
+        am = self._amax_of(x, n * h * w, c, scale=scale, shift=shift, bnC=c)
+        return ops.split_padded(self._parts, x, scale, shift, self._padbuf(key, n, h, w, self._parts * c), n, h, w, c, amax=am), am
+
+    def _split_mat(self, x2d, rows, c, scale=None, shift=None, bnC=0):
+        am = self._amax_of(x2d, rows, c, scale=scale, shift=shift, bnC=bnC)
+        return ops.split_rows(self._parts, x2d, torch.empty(rows * self._parts * c, dtype=self._h16, device=x2d.device), rows, c,
+                              scale=scale, shift=shift, bnC=bnC, amax=am), am
 
     def _x6_linear5(self, n, k5):
         """precision="bf16x6": linear5's three contractions on split operands (>= 256 frames: the 256 x 256 tile)"""
-        return self._x6 and ops.linear_x6_ok(n, k5, 512) and os.environ.get("GOALNET_X6_OFF") != "1" and os.environ.get("GOALNET_X6_LINEAR5", "1") != "0"
+        return self._x6 and ops.linear_split_ok(self._parts, n, k5, 512) and os.environ.get("GOALNET_X6_OFF") != "1" and \
+            os.environ.get("GOALNET_X6_LINEAR5", "1") != "0"
 
     def _mlp_fused(self, n):
         """the one-launch fusion MLP (csrc/mlp.hip): the regression head at the reference's sub-batch sizes"""
@@ -670,10 +693,11 @@ class AVM(nn.Module):
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_bf16p_o16 if y16_2 else ops.conv3x3_fwd_bf16p,
                         xh1, w2b, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
         elif self._x6_conv(n * hp1 * wp1, 256):
-            x1s = ops.split3_padded(p1, st1[2], st1[3], self._padbuf("x1s" if save else "x1se", n, hp1, wp1, 192), n, hp1, wp1, 64)
-            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_x6,
-                        x1s, self._split_w(P("visbl.conv2.weight"), 256 * 9, 64), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
-            del x1s                                  # conv2's weight gradient stays on the fp32 kernel (3 output tiles: no gain)
+            x1s, ax = self._split_act("x1s" if save else "x1se", p1, st1[2], st1[3], n, hp1, wp1, 64)
+            w2s, aw = self._split_w(P("visbl.conv2.weight"), 256 * 9, 64)
+            self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_split, self._parts,
+                        x1s, w2s, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256, self._osc(ax, aw))
+            del x1s, w2s                             # conv2's weight gradient stays on the fp32 kernel (3 output tiles: no gain)
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
@@ -691,12 +715,13 @@ class AVM(nn.Module):
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_bf16p_o16 if y16_3 else ops.conv3x3_fwd_bf16p,
                         xh2, w3b, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
         elif self._x6_conv(n * hp2 * wp2, 256):
-            x2s = ops.split3_padded(p2, st2[2], st2[3], self._padbuf("x2s" if save else "x2se", n, hp2, wp2, 768), n, hp2, wp2, 256)
-            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_x6,
-                        x2s, self._split_w(P("visbl.conv3.weight"), 512 * 9, 256), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
+            x2s, ax = self._split_act("x2s" if save else "x2se", p2, st2[2], st2[3], n, hp2, wp2, 256)
+            w3s, aw = self._split_w(P("visbl.conv3.weight"), 512 * 9, 256)
+            self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd_split, self._parts,
+                        x2s, w3s, P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512, self._osc(ax, aw))
             if save:
-                ctx.update(x2s=x2s, x2s_gen=self._padgen["x2s"])
-            del x2s
+                ctx.update(x2s=x2s, x2s_amax=ax, x2s_gen=self._padgen["x2s"])
+            del x2s, w3s
         else:
             self._timed("conv_fwd", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_fwd,
                         p2, st2[2], st2[3], P("visbl.conv3.weight"), P("visbl.conv3.bias"), True, y3, n, hp2, wp2, 256, 512)
@@ -718,13 +743,12 @@ class AVM(nn.Module):
             del xh3, w5b
         elif self._x6_linear5(n, k5):
             # BatchNorm3 is applied in fp32 on the way into the split (one fmaf per value, as the fp32 kernel's load does)
-            x3s = ops.split3_rows(p3.view(n, k5), torch.empty(n * 3 * k5, dtype=torch.bfloat16, device=dev), n, k5,
-                                  scale=st3[2], shift=st3[3], bnC=512)
-            w5s = ops.split3_rows(P("visbl.linear5.weight").view(512, k5), torch.empty(512 * 3 * k5, dtype=torch.bfloat16, device=dev), 512, k5)
-            ops.linear_fwd_x6(x3s, w5s, P("visbl.linear5.bias"), cat[:, voff:], n, k5, 512, relu=True,
-                              dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:])
+            x3s, ax = self._split_mat(p3.view(n, k5), n, k5, scale=st3[2], shift=st3[3], bnC=512)
+            w5s, aw = self._split_mat(P("visbl.linear5.weight").view(512, k5), 512, k5)
+            ops.linear_fwd_split(self._parts, x3s, w5s, P("visbl.linear5.bias"), cat[:, voff:], n, k5, 512, relu=True,
+                                 dropmask=masks[0], mult_out=None if mcat is None else mcat[:, voff:], oscale=self._osc(ax, aw))
             if save:
-                ctx.update(x3s=x3s, w5s=w5s)
+                ctx.update(x3s=x3s, w5s=w5s, x3s_amax=ax, w5s_amax=aw)
             del x3s, w5s
         else:
             ops.linear_fwd(p3.view(n, k5), P("visbl.linear5.weight"), P("visbl.linear5.bias"), cat[:, voff:], relu=True,
@@ -933,10 +957,11 @@ class AVM(nn.Module):
             if after_linear5:
                 after_linear5(fork)
         elif "x3s" in ctx:
-            dz5s = ops.split3_rows(dz5, torch.empty(n * 1536, dtype=torch.bfloat16, device=dev), n, 512)
-            fork.run(lambda: ops.linear_bwd_dw_x6(dz5s, ctx["x3s"], G("visbl.linear5.weight"), n, k5, 512), dz5s)
+            dz5s, adz = self._split_mat(dz5, n, 512)
+            osc_w = self._osc(adz, ctx["x3s_amax"])
+            fork.run(lambda: ops.linear_bwd_dw_split(self._parts, dz5s, ctx["x3s"], G("visbl.linear5.weight"), n, k5, 512, oscale=osc_w), dz5s)
             bucket_done(1)
-            ops.linear_bwd_dx_x6(dz5s, ctx["w5s"], dbn3.view(n, k5), n, k5, 512)
+            ops.linear_bwd_dx_split(self._parts, dz5s, ctx["w5s"], dbn3.view(n, k5), n, k5, 512, oscale=self._osc(adz, ctx["w5s_amax"]))
             if after_linear5:
                 after_linear5(fork)
         else:
@@ -959,10 +984,11 @@ class AVM(nn.Module):
             if ctx["x2s_gen"] != self._padgen["x2s"]:
                 raise RuntimeError("precision='bf16x6': a second training-mode forward overwrote the saved split operands before "
                                    "backward ran; call backward after each forward (as the reference's loop does)")
-            # the weight gradient and the data gradient read the gradient as bf16 triples in the padded layout: one split pass
-            dys3 = ops.split3_padded(dy3, None, None, self._padbuf("dy3s", n, hp2, wp2, 1536), n, hp2, wp2, 512)
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_x6,
-                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dys3)
+            # the weight gradient and the data gradient read the gradient as 16-bit parts in the padded layout: one split pass
+            dys3, ady = self._split_act("dy3s", dy3, None, None, n, hp2, wp2, 512)
+            osc_w = self._osc(ady, ctx["x2s_amax"])
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_split, self._parts,
+                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512, osc_w), dys3)
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
                                          ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
@@ -982,9 +1008,10 @@ class AVM(nn.Module):
                 self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_bf16p,
                             dyp3, wtb, None, False, dbn2, n, hp2, wp2, 512, 256)
         elif x6_3:
-            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_x6,
-                        dys3, self._split_w(wt, 256 * 9, 512), None, False, dbn2, n, hp2, wp2, 512, 256)
-            del dys3
+            wts, awt = self._split_w(wt, 256 * 9, 512)
+            self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd_split, self._parts,
+                        dys3, wts, None, False, dbn2, n, hp2, wp2, 512, 256, self._osc(ady, awt))
+            del dys3, wts
         else:
             self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
                         dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)

@@ -63,23 +63,30 @@ __device__ __forceinline__ int tile_row_of(int h, int lr) { return (lr / GROUP) 
 //   A part:  mid        hi        lo        hi         mid        hi          SEGMAP_A = 0x010201
 //   B part:  mid        lo        hi        mid        hi         hi          SEGMAP_B = 0x001021
 constexpr unsigned SEGMAP_A = 0x010201u, SEGMAP_B = 0x001021u;
-// The segments are the FAST index of the reduction: virtual chunk = 6 * (64-channel chunk) + s (convolutions), K-tile =
-// 6 * (64-pixel tile) + s (weight gradient), so that the six products of one piece of the operands run back to back and its
+// "fp16x3": two fp16 parts [hi | mid] of the value scaled by a power of two (11 + 11 significand bits), three partial products
+//        s:   0          1         2
+//   A part:  hi         mid       hi           SEGMAP_A3 = 0x010
+//   B part:  mid        hi        hi           SEGMAP_B3 = 0x001
+constexpr unsigned SEGMAP_A3 = 0x010u, SEGMAP_B3 = 0x001u;
+// The segments are the FAST index of the reduction: virtual chunk = NSEG * (64-channel chunk) + s (convolutions), K-tile =
+// NSEG * (64-pixel tile) + s (weight gradient), so that the products of one piece of the operands run back to back and its
 // parts are fetched from HBM once (with the segment as the slow index every part was streamed two to three times:
 // conv3's weight gradient 78.9 ms).
-// first stored channel of virtual 64-channel chunk `chunk` (segC channels per part); past the end: >= 3 segC or harmless
+// first stored channel of virtual 64-channel chunk `chunk` (segC channels per part); past the end: >= the stored channels or harmless
+template <int NSEG>
 __device__ __forceinline__ int seg_channel(int chunk, int segC, unsigned segmap) {
-    const int cc = chunk / 6, seg = chunk - 6 * cc;
+    const int cc = chunk / NSEG, seg = chunk - NSEG * cc;
     return (int)((segmap >> (4 * seg)) & 15u) * segC + cc * BKH;
 }
 
 // K-contiguous bf16 matrix X[rows][K] (weights [Cout][9*Cin]); wave w issues pieces 2w, 2w+1 of a half-tile
-template <int GROUP, bool SEG = false>
+template <int GROUP, int NSEG = 0>
 struct KCLoader256 {
     // convC > 0: K-tiles in (channel chunk, tap) order over rows of 9 x convC values. segC > 0 (split operands, SegMap below):
     // convC = 3 segC stored channels [hi | mid | lo] per tap, 6 segC virtual ones
     struct P { const __hip_bfloat16* x; int64_t ld; int rows; int convC; int segC; unsigned segmap; };
     static constexpr bool TR = false;
+    static constexpr int NSEGS = NSEG;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
     int wave, convC, segC;
@@ -104,7 +111,7 @@ struct KCLoader256 {
         // the k range of K-tile kt: plain = [64 kt, +64); convolution order = tap (kt % 9), channels 64 (kt / 9) .. +63
         unsigned koff = convC > 0 ? (unsigned)((kt % 9) * convC + (kt / 9) * BKH) : (unsigned)kt * BKH;
         // split operands: convolution order as above over 6 x the chunks; plain order = rows [hi K | mid K | lo K], K-tile = 6 * (64-column tile) + segment
-        if constexpr (SEG) koff = convC > 0 ? (unsigned)((kt % 9) * convC + seg_channel(kt / 9, segC, segmap)) : (unsigned)seg_channel(kt, segC, segmap);
+        if constexpr (NSEG > 0) koff = convC > 0 ? (unsigned)((kt % 9) * convC + seg_channel<NSEG>(kt / 9, segC, segmap)) : (unsigned)seg_channel<NSEG>(kt, segC, segmap);
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 8 * ROWB, voff[h][i], koff * 2);
     }
@@ -112,10 +119,11 @@ struct KCLoader256 {
 
 // im2col of a zero-padded bf16 NHWC tensor (buffer convention of gemm_bf16.hip: `x` = padded pixel 0, W+3 zero guard pixels
 // in front and behind): row m = (n,h,w) of the output grid, k = (kh,kw,ci); no validity masks.
-template <int GROUP, bool SEG = false>
+template <int GROUP, int NSEG = 0>
 struct ConvAPadLoader256 {
-    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; int segC; unsigned segmap; };   // segC > 0: C = 3 segC stored channels (split operands)
+    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; int segC; unsigned segmap; };   // segC > 0: C = 2 or 3 segC stored channels (split operands)
     static constexpr bool TR = false;
+    static constexpr int NSEGS = NSEG;
     __amdgpu_buffer_rsrc_t rx;
     unsigned voff[2][2];
     int Wp2, C, wave, segC;
@@ -154,7 +162,7 @@ struct ConvAPadLoader256 {
         // XCD at C = 512) and the data gradient re-fetched its input 5x from the fabric (profiles/r01_bf16_traffic.md).
         const int chunk = kt / 9, tap = kt - 9 * chunk;
         int ci = chunk * BKH;
-        if constexpr (SEG) ci = seg_channel(chunk, segC, segmap);
+        if constexpr (NSEG > 0) ci = seg_channel<NSEG>(chunk, segC, segmap);
         const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;                  // tap / 3 for tap < 16
         // past the last K-tile (ci >= C) the offset only has to stay harmless: the range check turns it into zeros
         const unsigned s0 = ci < C ? (unsigned)(((kh * Wp2 + kw) * C + ci) * 2) : OOB;
@@ -211,12 +219,13 @@ __device__ __forceinline__ bf16x8 rd_tr(const unsigned (&ad)[2]) {
     DST[2] = rd_tr<(S) * HALF_BYTES + 2 * 16 * TROWB>(AD); DST[3] = rd_tr<(S) * HALF_BYTES + 3 * 16 * TROWB>(AD);
 
 // plain matrix X[kred][cols] (dy_pad [pixels][Cout]): re-based every K-tile; rows past kred / columns past `cols` read 0
-template <bool SEG>
+template <int NSEG>
 struct MCLoader256T {
-    // SEG (split operands, segKT > 0): K-tile kt = 6 * (64-row tile) + segment s; segment s reads the columns of part
+    // NSEG > 0 (split operands, segKT > 0): K-tile kt = 6 * (64-row tile) + segment s; segment s reads the columns of part
     // (segmap >> 4 s) & 15, segC columns further right each (ld = 3 segC)
     struct P { const __hip_bfloat16* x; int64_t ld; int cols; int64_t kred; int segKT; int segC; unsigned segmap; };
     static constexpr bool TR = true;
+    static constexpr int NSEGS = NSEG;
     const __hip_bfloat16* x;
     int64_t ld, kred;
     int wave, segKT, segC;
@@ -238,7 +247,7 @@ struct MCLoader256T {
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
         int kk = kt;
         unsigned soff = 0u;
-        if constexpr (SEG) { kk = kt / 6; soff = ((segmap >> (4 * (kt - 6 * kk))) & 15u) * (unsigned)segC * 2u; }
+        if constexpr (NSEG > 0) { kk = kt / NSEG; soff = ((segmap >> (4 * (kt - NSEG * kk))) & 15u) * (unsigned)segC * 2u; }
         const int64_t kbase = (int64_t)kk * BKH;                             // past the last tile: empty range below
         const int64_t nk = kred - kbase < BKH ? kred - kbase : BKH;          // <= 0 past the end: empty range, zeros
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + kbase * ld, clamp_u32(nk * ld * 2));
@@ -247,16 +256,17 @@ struct MCLoader256T {
     }
 };
 
-typedef MCLoader256T<false> MCLoader256;
+typedef MCLoader256T<0> MCLoader256;
 
 // B operand of the weight gradient on the zero-padded pixel grid: B(col = (tap, ci), k = pm) = x_pad[pm + shift(tap)][ci]
 // (constant pixel shift per tap; pad pixels contribute nothing because dy_pad is zero there). `x` = padded pixel 0 of a
 // buffer with W+3 zero guard pixels in front and behind.
-template <bool SEG>
+template <int NSEG>
 struct ConvWgradBLoader256T {
-    // SEG (split operands, segKT > 0): Cs = 3 C stored channels per pixel, K-tile kt = 6 * (64-pixel tile) + segment
+    // NSEG > 0 (split operands, segKT > 0): Cs = 3 C stored channels per pixel, K-tile kt = 6 * (64-pixel tile) + segment
     struct P { const __hip_bfloat16* x; int Wp2, C; int64_t Mp; int Cs; int segKT; unsigned segmap; };
     static constexpr bool TR = true;
+    static constexpr int NSEGS = NSEG;
     const __hip_bfloat16* x;
     int64_t Mp;
     int C, G, wave, Cs, segKT;
@@ -284,7 +294,7 @@ struct ConvWgradBLoader256T {
     __device__ __forceinline__ void issue(int kt, int h, char* l) const {
         int kk = kt;
         unsigned soff = 0u;
-        if constexpr (SEG) { kk = kt / 6; soff = ((segmap >> (4 * (kt - 6 * kk))) & 15u) * (unsigned)C * 2u; }
+        if constexpr (NSEG > 0) { kk = kt / NSEG; soff = ((segmap >> (4 * (kt - NSEG * kk))) & 15u) * (unsigned)C * 2u; }
         const int64_t kbase = (int64_t)kk * BKH;
         // K-tiles past the pixel grid (staged only to keep the DMA counts uniform) get an empty range: zeros, no access
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + (kbase - G) * Cs, kbase < Mp ? (uint32_t)((BKH + 2 * G) * Cs * 2) : 0u);
@@ -292,7 +302,7 @@ struct ConvWgradBLoader256T {
         for (int i = 0; i < 2; ++i) dma16(rx, l + (wave * 2 + i) * 4 * TROWB, voff[h][i], soff);
     }
 };
-typedef ConvWgradBLoader256T<false> ConvWgradBLoader256;
+typedef ConvWgradBLoader256T<0> ConvWgradBLoader256;
 
 __device__ __forceinline__ bf16x8 read_frag(const char* half, int row0, int ks, int lane) {
     return *reinterpret_cast<const bf16x8*>(half + kc_boff(row0 + (lane & 31), 2 * ks + (lane >> 5)));
@@ -356,6 +366,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // WALK: the block goes on to the virtual blocks L + gridDim.x, ... (launch_256_t launches one block per CU for these roles);
     // the other roles run one tile per block and compile without the hand-over (no register pressure from it, no spills).
     constexpr bool WALK = walks_tiles(ROLE);
+    // fp16x3 (three segments): the operands were scaled by powers of two, oscale = {their product, its inverse} (EpiP)
+    constexpr bool OSC = AL::NSEGS == 3;
+    float osc_mul = 1.f, osc_inv = 1.f;
+    if constexpr (OSC) { if (ep.oscale) { osc_mul = ep.oscale[0]; osc_inv = ep.oscale[1]; } }
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,11 +410,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     if constexpr (ROLE == 0) {                                                                              \
         if constexpr (SWAP) {                                                                               \
             bias_t = 0.f;                                                                                   \
-            if (ep.bias && tid < T && tn * T + tid < ep.cols) bias_t = ep.bias[tn * T + tid];               \
+            if (ep.bias && tid < T && tn * T + tid < ep.cols) bias_t = ep.bias[tn * T + tid] * osc_mul;     \
         } else {                                                                                            \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                 \
                 const int colj = tn * T + wc * 64 + j * 32 + (lane & 31);                                   \
-                bias_col[j] = ep.bias && colj < ep.cols ? ep.bias[colj] : 0.f;                              \
+                bias_col[j] = ep.bias && colj < ep.cols ? ep.bias[colj] * osc_mul : 0.f;                    \
             }                                                                                               \
         }                                                                                                   \
     }
@@ -546,6 +560,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // what is left to do per value: ROLE 0 (conv forward) clamps at 0 when ReLU is on (its bias is already in); the
     // other roles store the accumulator as it is (their callers pass no bias and no ReLU)
     auto fin = [&](float v) -> float {
+        if constexpr (OSC) v *= osc_inv;
         if constexpr (ROLE == 0) return ep.relu ? fmaxf(v, 0.f) : v;
         else return v;
     };
@@ -839,23 +854,37 @@ int launch_wgrad_bf16_256(const char* name, const __hip_bfloat16* x_pad, const _
     return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, f16, st);
 }
 
-// ---- split operands (bf16x6): the same kernels over 6 K-segments of [hi | mid | lo] operands (comment at SEGMAP_A) ------------
-// conv 3x3 forward / data gradient: x_pad3 = zero-padded [pixels][3 Cin], w3 = [Cout][9][3 Cin]; fp32 result
-int launch_conv_x6_256(const char* name, const __hip_bfloat16* x_pad3, int H, int W, int Cin, int64_t M, const __hip_bfloat16* w3,
-                       int Cout, const EpiP& ep, hipStream_t st) {
-    typedef ConvAPadLoader256<64, true> AL;
-    typedef KCLoader256<32, true> BL;
+// ---- split operands: the same kernels over NSEG K-segments of [hi | mid | lo] (bf16x6: 3 parts, 6 segments) or [hi | mid]
+// (fp16x3: 2 parts of the power-of-two-scaled value, 3 segments, ep.oscale) operands (comment at SEGMAP_A) ----------------------
+template <int NSEG> struct SegCfg;
+template <> struct SegCfg<6> { static constexpr int PARTS = 3; static constexpr unsigned A = SEGMAP_A, B = SEGMAP_B; static constexpr bool F16 = false; };
+template <> struct SegCfg<3> { static constexpr int PARTS = 2; static constexpr unsigned A = SEGMAP_A3, B = SEGMAP_B3; static constexpr bool F16 = true; };
+
+// conv 3x3 forward / data gradient: x_pads = zero-padded [pixels][PARTS Cin], ws = [Cout][9][PARTS Cin]; fp32 result
+template <int NSEG>
+static int launch_conv_split_t(const char* name, const __hip_bfloat16* x_pads, int H, int W, int Cin, int64_t M, const __hip_bfloat16* ws,
+                               int Cout, const EpiP& ep, hipStream_t st) {
+    typedef ConvAPadLoader256<64, NSEG> AL;
+    typedef KCLoader256<32, NSEG> BL;
+    typedef SegCfg<NSEG> S;
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (Cout + T - 1) / T;
-    AL::P ap{x_pad3, H, W, 3 * Cin, M, Cin, SEGMAP_A};
-    BL::P bp{w3, (int64_t)9 * 3 * Cin, Cout, 3 * Cin, Cin, SEGMAP_B};
-    const int kt = 9 * 6 * Cin / BKH;
-    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias) ? launch_256<AL, BL, 0>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, false, st)
-                                                            : launch_256<AL, BL, 1>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, false, st);
+    typename AL::P ap{x_pads, H, W, S::PARTS * Cin, M, Cin, S::A};
+    typename BL::P bp{ws, (int64_t)9 * S::PARTS * Cin, Cout, S::PARTS * Cin, Cin, S::B};
+    const int kt = 9 * NSEG * Cin / BKH;
+    return ep.mode == EPI_BIAS_RELU && (ep.relu || ep.bias)
+        ? launch_256_t<AL, BL, 0, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, st)
+        : launch_256_t<AL, BL, 1, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 0, kt, kt, st);
+}
+int launch_conv_split_256(const char* name, int parts, const __hip_bfloat16* x_pads, int H, int W, int Cin, int64_t M,
+                          const __hip_bfloat16* ws, int Cout, const EpiP& ep, hipStream_t st) {
+    return parts == 3 ? launch_conv_split_t<6>(name, x_pads, H, W, Cin, M, ws, Cout, ep, st)
+                      : launch_conv_split_t<3>(name, x_pads, H, W, Cin, M, ws, Cout, ep, st);
 }
 
-int wgrad_x6_splits_256(int64_t Mp, int Cin, int Cout) {
+int wgrad_split_splits_256(int parts, int64_t Mp, int Cin, int Cout) {
+    const int nseg = parts == 3 ? 6 : 3;
     const int64_t tiles = (int64_t)((Cout + T - 1) / T) * ((9 * Cin + T - 1) / T);
-    const int ktiles = 6 * (int)((Mp + BKH - 1) / BKH);
+    const int ktiles = nseg * (int)((Mp + BKH - 1) / BKH);
     int64_t s = (2048 + tiles - 1) / tiles;
     const int64_t smax = ktiles / 64 > 1 ? ktiles / 64 : 1;
     if (s > smax) s = smax;
@@ -866,61 +895,91 @@ int wgrad_x6_splits_256(int64_t Mp, int Cin, int Cout) {
     return (ktiles + kps - 1) / kps;
 }
 
-// conv 3x3 weight gradient: dy_pad3 = [padded pixels][3 Cout], x_pad3 = [padded pixels][3 Cin]; slabs[split][Cout][9 Cin]
-int launch_wgrad_x6_256(const char* name, const __hip_bfloat16* x_pad3, const __hip_bfloat16* dy_pad3, int Wp2, int Cin, int Cout,
-                        int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
-    typedef MCLoader256T<true> AL;
-    typedef ConvWgradBLoader256T<true> BL;
+// conv 3x3 weight gradient: dy_pads = [padded pixels][PARTS Cout], x_pads = [padded pixels][PARTS Cin]; slabs[split][Cout][9 Cin]
+template <int NSEG>
+static int launch_wgrad_split_t(const char* name, const __hip_bfloat16* x_pads, const __hip_bfloat16* dy_pads, int Wp2, int Cin, int Cout,
+                                int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
+    typedef MCLoader256T<NSEG> AL;
+    typedef ConvWgradBLoader256T<NSEG> BL;
+    typedef SegCfg<NSEG> S;
     const int64_t tiles_m = (Cout + T - 1) / T, tiles_n = (9 * Cin + T - 1) / T;
-    const int seg_kt = (int)((Mp + BKH - 1) / BKH), ktiles = 6 * seg_kt;
+    const int seg_kt = (int)((Mp + BKH - 1) / BKH), ktiles = NSEG * seg_kt;
     GN_REQUIRE(nsplit >= 1 && nsplit <= 65535, GOALNET_E_SHAPE, "%s: bad split count %d", name, nsplit);
     const int kps = (ktiles + nsplit - 1) / nsplit;
-    AL::P ap{dy_pad3, (int64_t)3 * Cout, Cout, Mp, seg_kt, Cout, SEGMAP_A};
-    BL::P bp{x_pad3, Wp2, Cin, Mp, 3 * Cin, seg_kt, SEGMAP_B};
+    typename AL::P ap{dy_pads, (int64_t)S::PARTS * Cout, Cout, Mp, seg_kt, Cout, S::A};
+    typename BL::P bp{x_pads, Wp2, Cin, Mp, S::PARTS * Cin, seg_kt, S::B};
     EpiP ep{EPI_RAW, slabs, (int64_t)9 * Cin, Cout, 9 * Cin, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)Cout * 9 * Cin};
-    return launch_256<AL, BL, 2>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, false, st);
+    return launch_256_t<AL, BL, 2, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, st);
+}
+int launch_wgrad_split_256(const char* name, int parts, const __hip_bfloat16* x_pads, const __hip_bfloat16* dy_pads, int Wp2, int Cin,
+                           int Cout, int64_t Mp, float* slabs, int nsplit, hipStream_t st) {
+    return parts == 3 ? launch_wgrad_split_t<6>(name, x_pads, dy_pads, Wp2, Cin, Cout, Mp, slabs, nsplit, st)
+                      : launch_wgrad_split_t<3>(name, x_pads, dy_pads, Wp2, Cin, Cout, Mp, slabs, nsplit, st);
 }
 
-// linear5 on split operands: x3s [M][3 K], w3s [J][3 K], dy3s [M][3 J] (parts side by side along the row)
-int linear_fwd_x6_splits_256(int M, int64_t K, int J) {
-    return splits_for_256((int64_t)((M + T - 1) / T) * ((J + T - 1) / T), (int)(6 * K / BKH));
+// linear5 on split operands: xs [M][PARTS K], ws [J][PARTS K], dys [M][PARTS J] (parts side by side along the row)
+int linear_fwd_split_splits_256(int parts, int M, int64_t K, int J) {
+    return splits_for_256((int64_t)((M + T - 1) / T) * ((J + T - 1) / T), (int)((parts == 3 ? 6 : 3) * K / BKH));
 }
 
-int launch_linear_fwd_x6_256(const char* name, const __hip_bfloat16* x3s, const __hip_bfloat16* w3s, int M, int64_t K, int J, float* slabs,
-                             int nsplit, hipStream_t st) {
-    typedef KCLoader256<64, true> AL;
-    typedef KCLoader256<32, true> BL;
+template <int NSEG>
+static int launch_linear_fwd_split_t(const char* name, const __hip_bfloat16* xs, const __hip_bfloat16* ws, int M, int64_t K, int J,
+                                     float* slabs, int nsplit, hipStream_t st) {
+    typedef KCLoader256<64, NSEG> AL;
+    typedef KCLoader256<32, NSEG> BL;
+    typedef SegCfg<NSEG> S;
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (J + T - 1) / T;
-    const int ktiles = (int)(6 * K / BKH);
+    const int ktiles = (int)(NSEG * K / BKH);
     const int kps = (ktiles + nsplit - 1) / nsplit;
-    AL::P ap{x3s, 3 * K, M, 0, (int)K, SEGMAP_A};
-    BL::P bp{w3s, 3 * K, J, 0, (int)K, SEGMAP_B};
+    typename AL::P ap{xs, S::PARTS * K, M, 0, (int)K, S::A};
+    typename BL::P bp{ws, S::PARTS * K, J, 0, (int)K, S::B};
     EpiP ep{EPI_RAW, slabs, J, M, J, nullptr, 0, nullptr, 0, nullptr, 0, (int64_t)M * J};
-    return launch_256<AL, BL, 3>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, false, st);
+    return launch_256_t<AL, BL, 3, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, nsplit, 1, ktiles, kps, st);
+}
+int launch_linear_fwd_split_256(const char* name, int parts, const __hip_bfloat16* xs, const __hip_bfloat16* ws, int M, int64_t K, int J,
+                                float* slabs, int nsplit, hipStream_t st) {
+    return parts == 3 ? launch_linear_fwd_split_t<6>(name, xs, ws, M, K, J, slabs, nsplit, st)
+                      : launch_linear_fwd_split_t<3>(name, xs, ws, M, K, J, slabs, nsplit, st);
 }
 
-int launch_linear_dx_x6_256(const char* name, const __hip_bfloat16* dy3s, const __hip_bfloat16* w3s, int M, int64_t K, int J, float* dx,
-                            int64_t lddx, hipStream_t st) {
-    typedef KCLoader256<64, true> AL;
-    typedef MCLoader256T<true> BL;
+template <int NSEG>
+static int launch_linear_dx_split_t(const char* name, const __hip_bfloat16* dys, const __hip_bfloat16* ws, int M, int64_t K, int J, float* dx,
+                                    int64_t lddx, const float* oscale, hipStream_t st) {
+    typedef KCLoader256<64, NSEG> AL;
+    typedef MCLoader256T<NSEG> BL;
+    typedef SegCfg<NSEG> S;
     const int64_t tiles_m = (M + T - 1) / T, tiles_n = (K + T - 1) / T;
-    const int ktiles = 6 * J / BKH;
-    AL::P ap{dy3s, (int64_t)3 * J, M, 0, J, SEGMAP_A};
-    BL::P bp{w3s, 3 * K, (int)K, J, 1, (int)K, SEGMAP_B};
+    const int ktiles = NSEG * J / BKH;
+    typename AL::P ap{dys, (int64_t)S::PARTS * J, M, 0, J, S::A};
+    typename BL::P bp{ws, S::PARTS * K, (int)K, J, 1, (int)K, S::B};
     EpiP ep{EPI_RAW, dx, lddx, M, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr};
-    return launch_256<AL, BL, 4>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, false, st);
+    ep.oscale = oscale;
+    return launch_256_t<AL, BL, 4, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, st);
+}
+int launch_linear_dx_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* ws, int M, int64_t K, int J,
+                               float* dx, int64_t lddx, const float* oscale, hipStream_t st) {
+    return parts == 3 ? launch_linear_dx_split_t<6>(name, dys, ws, M, K, J, dx, lddx, oscale, st)
+                      : launch_linear_dx_split_t<3>(name, dys, ws, M, K, J, dx, lddx, oscale, st);
 }
 
-int launch_linear_dw_x6_256(const char* name, const __hip_bfloat16* dy3s, const __hip_bfloat16* x3s, int M, int64_t K, int J, float* dw,
-                            hipStream_t st) {
-    typedef MCLoader256T<true> AL;
-    typedef MCLoader256T<true> BL;
+template <int NSEG>
+static int launch_linear_dw_split_t(const char* name, const __hip_bfloat16* dys, const __hip_bfloat16* xs, int M, int64_t K, int J, float* dw,
+                                    const float* oscale, hipStream_t st) {
+    typedef MCLoader256T<NSEG> AL;
+    typedef MCLoader256T<NSEG> BL;
+    typedef SegCfg<NSEG> S;
     const int64_t tiles_m = (J + T - 1) / T, tiles_n = (K + T - 1) / T;
-    const int ktiles = 6 * ((M + BKH - 1) / BKH);
-    AL::P ap{dy3s, (int64_t)3 * J, J, M, 1, J, SEGMAP_A};
-    BL::P bp{x3s, 3 * K, (int)K, M, 1, (int)K, SEGMAP_B};
+    const int ktiles = NSEG * ((M + BKH - 1) / BKH);
+    typename AL::P ap{dys, (int64_t)S::PARTS * J, J, M, 1, J, S::A};
+    typename BL::P bp{xs, S::PARTS * K, (int)K, M, 1, (int)K, S::B};
     EpiP ep{EPI_RAW, dw, K, J, (int)K, nullptr, 0, nullptr, 0, nullptr, 0, 0};
-    return launch_256<AL, BL, 5>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, false, st);
+    ep.oscale = oscale;
+    return launch_256_t<AL, BL, 5, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, st);
+}
+int launch_linear_dw_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* xs, int M, int64_t K, int J,
+                               float* dw, const float* oscale, hipStream_t st) {
+    return parts == 3 ? launch_linear_dw_split_t<6>(name, dys, xs, M, K, J, dw, oscale, st)
+                      : launch_linear_dw_split_t<3>(name, dys, xs, M, K, J, dw, oscale, st);
 }
 
 }  // namespace goalnet

@@ -31,9 +31,13 @@ struct EpiP {
     // sums the tile's slabs in split order (the order of splitk_reduce_kernel: same bits) and applies this epilogue (out, ld,
     // bias, relu, mul, mult_out) — no second launch. tile_ctr[] must be zero on entry and is zero again on exit.
     float* slabs; int* tile_ctr;
+    // split operands in fp16 (csrc/split3.hip, "fp16x3"): the GEMM ran on operands scaled by powers of two; oscale[0] = their product,
+    // oscale[1] = its inverse (device memory, written by goalnet_split_scales). Applied to the accumulated value before bias / ReLU.
+    const float* oscale = nullptr;
 };
 
 __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {
+    if (e.oscale) v *= e.oscale[1];
     if (e.bias) v += e.bias[col];
     float g = 1.f;
     if (e.relu) { g = v > 0.f ? 1.f : 0.f; v = v > 0.f ? v : 0.f; }

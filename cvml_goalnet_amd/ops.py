@@ -31,7 +31,7 @@ def _chk(*ts):
             continue
         if not t.is_cuda:
             raise _lib.GoalnetError("expected a GPU tensor")
-        if t.dtype not in (F32, torch.float64, torch.uint8, torch.bfloat16, torch.float16):
+        if t.dtype not in (F32, torch.float64, torch.uint8, torch.bfloat16, torch.float16, torch.int32):
             raise _lib.GoalnetError(f"unexpected dtype {t.dtype}")
 
 
@@ -413,76 +413,107 @@ def conv3x3_wgrad_bf16(xpad, dypad, dw, N, H, W, Cin, Cout):
     return dw
 
 
-# ---- precision = "bf16x6" (csrc/split3.hip): fp32 operands as [hi | mid | lo] bf16 triples, six partial products per product ----
-def split3_padded(x, scale, shift, ypad3, N, H, W, C):
-    """x fp32 (N,H,W,C) [* scale + shift per channel] -> interior of the zero-padded (N,H+2,W+2,3C) bf16 view `ypad3`"""
-    _chk(x, scale, shift, ypad3)
-    _req(x.dtype == F32 and ypad3.dtype == torch.bfloat16 and x.numel() == N * H * W * C and ypad3.numel() >= N * (H + 2) * (W + 2) * 3 * C,
-         "split3_padded: x fp32 (N,H,W,C), ypad3 bf16 (N,H+2,W+2,3C)")
-    check(lib().goalnet_split3_padded(x.data_ptr(), _p(scale), _p(shift), ypad3.data_ptr(), N, H, W, C, _s()), "split3_padded")
-    return ypad3
+# ---- precision = "bf16x6" / "fp16x3" (csrc/split3.hip): fp32 operands as bf16 triples (parts = 3, six partial products per product) or
+# as fp16 pairs of the power-of-two-scaled value (parts = 2, three partial products; `amax` = the tensor's magnitude word, `oscale` =
+# the two operands' combined scale and its inverse for the GEMM epilogue)
+def _part_dtype(parts):
+    _req(parts in (2, 3), "parts must be 3 (bf16 triples) or 2 (scaled fp16 pairs)")
+    return torch.bfloat16 if parts == 3 else torch.float16
 
 
-def split3_rows(x, y3, rows, C, scale=None, shift=None, bnC=0):
-    """x fp32 (rows, C) (row stride = x's leading dim when 2-D) [* scale + shift with channel = column % bnC] -> y3 bf16 [rows][3C]"""
-    _chk(x, y3, scale, shift)
-    _req(x.dtype == F32 and y3.dtype == torch.bfloat16 and y3.numel() == 3 * rows * C, "split3_rows: sizes / dtypes")
+def absmax(x, amax, rows, C, scale=None, shift=None, bnC=0):
+    """atomic max of the bit pattern of |x * scale + shift| over a (rows, C) fp32 matrix into the int32 word `amax` (zeroed by the caller)"""
+    _chk(x, amax, scale, shift)
+    _req(x.dtype == F32 and amax.dtype == torch.int32 and amax.numel() == 1 and x.numel() >= rows * C, "absmax: sizes / dtypes")
     ldx = _ld(x) if x.dim() == 2 else C
-    _req(x.dim() == 2 and tuple(x.shape) == (rows, C) or x.numel() == rows * C, "split3_rows: x must hold rows x C values")
-    check(lib().goalnet_split3_rows(x.data_ptr(), ldx, _p(scale), _p(shift), bnC, y3.data_ptr(), rows, C, _s()), "split3_rows")
-    return y3
+    check(lib().goalnet_absmax(x.data_ptr(), ldx, _p(scale), _p(shift), bnC, rows, C, amax.data_ptr(), _s()), "absmax")
+    return amax
 
 
-def linear_x6_ok(M, K, J) -> bool:
-    return bool(lib().goalnet_linear_x6_ok(M, K, J))
+def split_scales(amax_a, amax_b, oscale=None):
+    """oscale = (s_a s_b, 1 / (s_a s_b)) on the device, from the two operands' magnitude words"""
+    oscale = torch.empty(2, dtype=F32, device=amax_a.device) if oscale is None else oscale
+    _chk(amax_a, amax_b, oscale)
+    check(lib().goalnet_split_scales(amax_a.data_ptr(), amax_b.data_ptr(), oscale.data_ptr(), _s()), "split_scales")
+    return oscale
 
 
-def linear_fwd_x6(x3s, w3s, bias, y, M, K, J, *, relu=False, dropmask=None, mult_out=None):
-    """y (M,J view, fp32) from the split operands x3s [M][3K], w3s [J][3K]"""
-    _chk(x3s, w3s, bias, y, dropmask, mult_out)
-    _req(x3s.dtype == torch.bfloat16 and w3s.dtype == torch.bfloat16 and x3s.numel() == 3 * M * K and w3s.numel() == 3 * J * K
-         and tuple(y.shape) == (M, J), "linear_fwd_x6: sizes / dtypes")
-    nbytes = lib().goalnet_linear_fwd_x6_ws_bytes(M, K, J)
-    _req(nbytes > 0, "linear_fwd_x6: dims not served (linear_x6_ok)")
-    ws = torch.empty(nbytes // 4, dtype=F32, device=y.device)
-    check(lib().goalnet_linear_fwd_x6(x3s.data_ptr(), w3s.data_ptr(), _p(bias), int(relu), _p(dropmask), 0 if dropmask is None else _ld(dropmask),
-                                      y.data_ptr(), _ld(y), _p(mult_out), 0 if mult_out is None else _ld(mult_out), M, K, J, ws.data_ptr(), nbytes, _s()),
-          "linear_fwd_x6")
+def split_padded(parts, x, scale, shift, ypads, N, H, W, C, amax=None):
+    """x fp32 (N,H,W,C) [* scale + shift per channel] -> interior of the zero-padded (N,H+2,W+2,parts C) 16-bit view `ypads`"""
+    _chk(x, scale, shift, ypads, amax)
+    _req(x.dtype == F32 and ypads.dtype == _part_dtype(parts) and x.numel() == N * H * W * C and ypads.numel() >= N * (H + 2) * (W + 2) * parts * C
+         and (parts == 3 or amax is not None), "split_padded: x fp32 (N,H,W,C), ypads 16-bit (N,H+2,W+2,parts C); parts = 2 needs amax")
+    check(lib().goalnet_split_padded(parts, x.data_ptr(), _p(scale), _p(shift), _p(amax), ypads.data_ptr(), N, H, W, C, _s()), "split_padded")
+    return ypads
+
+
+def split_rows(parts, x, ys, rows, C, scale=None, shift=None, bnC=0, amax=None):
+    """x fp32 (rows, C) (row stride = x's leading dim when 2-D) [* scale + shift with channel = column % bnC] -> ys 16-bit [rows][parts C]"""
+    _chk(x, ys, scale, shift, amax)
+    _req(x.dtype == F32 and ys.dtype == _part_dtype(parts) and ys.numel() == parts * rows * C and (parts == 3 or amax is not None),
+         "split_rows: sizes / dtypes; parts = 2 needs amax")
+    ldx = _ld(x) if x.dim() == 2 else C
+    _req(x.dim() == 2 and tuple(x.shape) == (rows, C) or x.numel() == rows * C, "split_rows: x must hold rows x C values")
+    check(lib().goalnet_split_rows(parts, x.data_ptr(), ldx, _p(scale), _p(shift), bnC, _p(amax), ys.data_ptr(), rows, C, _s()), "split_rows")
+    return ys
+
+
+def linear_split_ok(parts, M, K, J) -> bool:
+    return bool(lib().goalnet_linear_split_ok(parts, M, K, J))
+
+
+def conv3x3_fwd_split(parts, xpads, ws, bias, relu, y, N, H, W, Cin, Cout, oscale=None):
+    _chk(xpads, ws, bias, y, oscale)
+    dt = _part_dtype(parts)
+    _req(xpads.dtype == dt and ws.dtype == dt and y.dtype == F32 and ws.numel() == Cout * 9 * parts * Cin and y.numel() == N * H * W * Cout
+         and xpads.numel() >= N * (H + 2) * (W + 2) * parts * Cin and (parts == 3 or oscale is not None), "conv3x3_fwd_split: sizes / dtypes")
+    check(lib().goalnet_conv3x3_fwd_split(parts, xpads.data_ptr(), ws.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _p(oscale), _s()),
+          "conv3x3_fwd_split")
     return y
 
 
-def linear_bwd_dx_x6(dy3s, w3s, dx, M, K, J):
-    _chk(dy3s, w3s, dx)
-    _req(dy3s.dtype == torch.bfloat16 and w3s.dtype == torch.bfloat16 and dx.dtype == F32 and dy3s.numel() == 3 * M * J and w3s.numel() == 3 * J * K
-         and tuple(dx.shape) == (M, K), "linear_bwd_dx_x6: sizes / dtypes")
-    check(lib().goalnet_linear_bwd_dx_x6(dy3s.data_ptr(), w3s.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _s()), "linear_bwd_dx_x6")
-    return dx
-
-
-def linear_bwd_dw_x6(dy3s, x3s, dw, M, K, J):
-    _chk(dy3s, x3s, dw)
-    _req(dy3s.dtype == torch.bfloat16 and x3s.dtype == torch.bfloat16 and dw.dtype == F32 and dy3s.numel() == 3 * M * J and x3s.numel() == 3 * M * K
-         and dw.numel() == J * K, "linear_bwd_dw_x6: sizes / dtypes")
-    check(lib().goalnet_linear_bwd_dw_x6(dy3s.data_ptr(), x3s.data_ptr(), dw.data_ptr(), M, K, J, _s()), "linear_bwd_dw_x6")
+def conv3x3_wgrad_split(parts, xpads, dypads, dw, N, H, W, Cin, Cout, oscale=None):
+    _chk(xpads, dypads, dw, oscale)
+    dt = _part_dtype(parts)
+    _req(xpads.dtype == dt and dypads.dtype == dt and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin and (parts == 3 or oscale is not None),
+         "conv3x3_wgrad_split: sizes / dtypes")
+    nbytes = lib().goalnet_conv3x3_wgrad_split_ws_bytes(parts, N, H, W, Cin, Cout)
+    ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
+    check(lib().goalnet_conv3x3_wgrad_split(parts, xpads.data_ptr(), dypads.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, N, H, W, Cin, Cout,
+                                            _p(oscale), _s()), "conv3x3_wgrad_split")
     return dw
 
 
-def conv3x3_fwd_x6(xpad3, w3, bias, relu, y, N, H, W, Cin, Cout):
-    _chk(xpad3, w3, bias, y)
-    _req(xpad3.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and y.dtype == F32 and w3.numel() == Cout * 27 * Cin
-         and y.numel() == N * H * W * Cout and xpad3.numel() >= N * (H + 2) * (W + 2) * 3 * Cin, "conv3x3_fwd_x6: sizes / dtypes")
-    check(lib().goalnet_conv3x3_fwd_x6(xpad3.data_ptr(), w3.data_ptr(), _p(bias), int(relu), y.data_ptr(), N, H, W, Cin, Cout, _s()), "conv3x3_fwd_x6")
+def linear_fwd_split(parts, xs, wsp, bias, y, M, K, J, *, relu=False, dropmask=None, mult_out=None, oscale=None):
+    """y (M,J view, fp32) from the split operands xs [M][parts K], wsp [J][parts K]"""
+    _chk(xs, wsp, bias, y, dropmask, mult_out, oscale)
+    dt = _part_dtype(parts)
+    _req(xs.dtype == dt and wsp.dtype == dt and xs.numel() == parts * M * K and wsp.numel() == parts * J * K and tuple(y.shape) == (M, J)
+         and (parts == 3 or oscale is not None), "linear_fwd_split: sizes / dtypes")
+    nbytes = lib().goalnet_linear_fwd_split_ws_bytes(parts, M, K, J)
+    _req(nbytes > 0, "linear_fwd_split: dims not served (linear_split_ok)")
+    ws = torch.empty(nbytes // 4, dtype=F32, device=y.device)
+    check(lib().goalnet_linear_fwd_split(parts, xs.data_ptr(), wsp.data_ptr(), _p(bias), int(relu), _p(dropmask), 0 if dropmask is None else _ld(dropmask),
+                                         y.data_ptr(), _ld(y), _p(mult_out), 0 if mult_out is None else _ld(mult_out), M, K, J, ws.data_ptr(), nbytes,
+                                         _p(oscale), _s()), "linear_fwd_split")
     return y
 
 
-def conv3x3_wgrad_x6(xpad3, dypad3, dw, N, H, W, Cin, Cout):
-    _chk(xpad3, dypad3, dw)
-    _req(xpad3.dtype == torch.bfloat16 and dypad3.dtype == torch.bfloat16 and dw.dtype == F32 and dw.numel() == Cout * 9 * Cin,
-         "conv3x3_wgrad_x6: sizes / dtypes")
-    nbytes = lib().goalnet_conv3x3_wgrad_x6_ws_bytes(N, H, W, Cin, Cout)
-    ws = torch.empty(nbytes // 4, dtype=F32, device=dw.device)
-    check(lib().goalnet_conv3x3_wgrad_x6(xpad3.data_ptr(), dypad3.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, N, H, W, Cin, Cout, _s()),
-          "conv3x3_wgrad_x6")
+def linear_bwd_dx_split(parts, dys, wsp, dx, M, K, J, oscale=None):
+    _chk(dys, wsp, dx, oscale)
+    dt = _part_dtype(parts)
+    _req(dys.dtype == dt and wsp.dtype == dt and dx.dtype == F32 and dys.numel() == parts * M * J and wsp.numel() == parts * J * K
+         and tuple(dx.shape) == (M, K) and (parts == 3 or oscale is not None), "linear_bwd_dx_split: sizes / dtypes")
+    check(lib().goalnet_linear_bwd_dx_split(parts, dys.data_ptr(), wsp.data_ptr(), dx.data_ptr(), _ld(dx), M, K, J, _p(oscale), _s()), "linear_bwd_dx_split")
+    return dx
+
+
+def linear_bwd_dw_split(parts, dys, xs, dw, M, K, J, oscale=None):
+    _chk(dys, xs, dw, oscale)
+    dt = _part_dtype(parts)
+    _req(dys.dtype == dt and xs.dtype == dt and dw.dtype == F32 and dys.numel() == parts * M * J and xs.numel() == parts * M * K
+         and dw.numel() == J * K and (parts == 3 or oscale is not None), "linear_bwd_dw_split: sizes / dtypes")
+    check(lib().goalnet_linear_bwd_dw_split(parts, dys.data_ptr(), xs.data_ptr(), dw.data_ptr(), M, K, J, _p(oscale), _s()), "linear_bwd_dw_split")
     return dw
 
 

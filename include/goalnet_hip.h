@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GOALNET_ABI_VERSION 3
+#define GOALNET_ABI_VERSION 4
 
 #define GOALNET_OK 0
 #define GOALNET_E_NULL (-1)      /* required pointer is NULL */
@@ -206,34 +206,43 @@ int goalnet_conv3x3_fwd_bf16p_o16(const void* x_pad, const void* w_bf16, const f
 size_t goalnet_conv3x3_wgrad_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw, void* ws, size_t ws_bytes,
                                int N, int H, int W, int Cin, int Cout, int f16, void* stream);
-/* ---- precision = "bf16x6" (csrc/split3.hip): the 3 x 3 convolutions of VisBl blocks 2 and 3 (/root/reference/utils.py:156-164,
- * 179-187; their backward, /root/reference/main.py:192) with fp32-grade products on the 16-bit MFMA. An fp32 operand value is
- * stored as three bf16 values hi + mid + lo (exact), [hi | mid | lo] along the channel axis; a convolution is ONE launch of the
- * 16-bit kernel over the six largest partial products as six K-segments, fp32 accumulation, fp32 result.
- *   split3_padded : x fp32 [N][H][W][C] (optional per-channel affine = the BatchNorm, applied in fp32) -> zero-padded
- *                   [N][H+2][W+2][3 C] bf16, interior only (borders / guards zeroed once by the caller, layout of to_bf16_padded)
- *   split3_rows   : x fp32 [rows][C] (row stride ldx; optional affine per column c with channel c % bnC) -> [rows][3 C] bf16
- *                   (weights [Cout][9][Cin] -> [Cout][9][3 Cin]; linear5's operands [M][K] -> [M][3 K])
- *   conv3x3_fwd_x6: y fp32 = act(conv(x, w) + bias); the data gradient = the same call on the split gradient and flipped weights
- *   conv3x3_wgrad_x6: dw fp32 [Cout][3][3][Cin] from split x and split dy (padded layouts) */
-int goalnet_split3_padded(const float* x, const float* scale, const float* shift, void* y_pad3, int N, int H, int W, int C, void* stream);
-int goalnet_split3_rows(const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, void* y3, int64_t rows, int64_t C,
-                        void* stream);
-int goalnet_conv3x3_fwd_x6(const void* x_pad3, const void* w3, const float* bias, int relu, float* y,
-                           int N, int H, int W, int Cin, int Cout, void* stream);
-size_t goalnet_conv3x3_wgrad_x6_ws_bytes(int N, int H, int W, int Cin, int Cout);
-int goalnet_conv3x3_wgrad_x6(const void* x_pad3, const void* dy_pad3, float* dw, void* ws, size_t ws_bytes,
-                             int N, int H, int W, int Cin, int Cout, void* stream);
-/* linear5 (/root/reference/utils.py:166-170, 189-193) on split operands, rows [hi | mid | lo] side by side: x3s [M][3 K], w3s [J][3 K],
- * dy3s [M][3 J]. goalnet_linear_x6_ok(M, K, J) says whether the dims are served (256 x 256 tile only); epilogue fields of the forward as
- * goalnet_linear_fwd_bf16; dx, dw fp32. */
-int goalnet_linear_x6_ok(int M, int64_t K, int J);
-size_t goalnet_linear_fwd_x6_ws_bytes(int M, int64_t K, int J);
-int goalnet_linear_fwd_x6(const void* x3s, const void* w3s, const float* bias, int relu, const float* dropmask, int64_t ldmask,
-                          float* y, int64_t ldy, float* mult_out, int64_t ldmult, int M, int64_t K, int J, void* ws, size_t ws_bytes,
-                          void* stream);
-int goalnet_linear_bwd_dx_x6(const void* dy3s, const void* w3s, float* dx, int64_t lddx, int M, int64_t K, int J, void* stream);
-int goalnet_linear_bwd_dw_x6(const void* dy3s, const void* x3s, float* dw, int M, int64_t K, int J, void* stream);
+/* ---- precision = "bf16x6" / "fp16x3" (csrc/split3.hip): the large GEMMs of VisBl (/root/reference/utils.py:156-170, 179-193; their
+ * backward, /root/reference/main.py:192) with fp32-grade products on the 16-bit MFMA. `parts` = 3: an fp32 operand value is stored as
+ * three bf16 values hi + mid + lo (exact), six partial products per product; `parts` = 2: as two fp16 values hi + mid of the value
+ * scaled by a power of two (22 significand bits; the scale puts the tensor's largest magnitude, goalnet_absmax, into [2^14, 2^15)),
+ * three partial products per product, and the epilogues undo the scales (`oscale` from goalnet_split_scales; NULL for parts = 3).
+ * The parts lie side by side along the channel / row axis; a GEMM is ONE launch of the 16-bit kernel with the partial products as
+ * K-segments, fp32 accumulation, fp32 result.
+ *   absmax        : atomic max of the bit pattern of |x[r][c] * scale[c % bnC] + shift[c % bnC]| into *amax_bits (zeroed by the caller)
+ *   split_scales  : oscale2[0] = s_a s_b, oscale2[1] = 1 / (s_a s_b) from the two operands' amax words
+ *   split_padded  : x fp32 [N][H][W][C] (optional per-channel affine = the BatchNorm, applied in fp32) -> zero-padded
+ *                   [N][H+2][W+2][parts C] 16-bit, interior only (borders / guards zeroed once by the caller, layout of to_bf16_padded)
+ *   split_rows    : x fp32 [rows][C] (row stride ldx; optional affine per column c with channel c % bnC) -> [rows][parts C] 16-bit
+ *                   (weights [Cout][9][Cin] -> [Cout][9][parts Cin]; linear5's operands [M][K] -> [M][parts K])
+ *   conv3x3_fwd_split: y fp32 = act(conv(x, w) + bias); the data gradient = the same call on the split gradient and flipped weights
+ *   conv3x3_wgrad_split: dw fp32 [Cout][3][3][Cin] from split x and split dy (padded layouts)
+ *   linear_*_split: linear5's forward (epilogue fields as goalnet_linear_fwd_bf16), dX and dW on xs [M][parts K], ws [J][parts K],
+ *                   dys [M][parts J]; goalnet_linear_split_ok says whether the dims are served (256 x 256 tile only) */
+int goalnet_absmax(const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, int64_t rows, int64_t C,
+                   unsigned* amax_bits, void* stream);
+int goalnet_split_scales(const unsigned* amax_a, const unsigned* amax_b, float* oscale2, void* stream);
+int goalnet_split_padded(int parts, const float* x, const float* scale, const float* shift, const unsigned* amax_bits, void* y_pads,
+                         int N, int H, int W, int C, void* stream);
+int goalnet_split_rows(int parts, const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, const unsigned* amax_bits,
+                       void* ys, int64_t rows, int64_t C, void* stream);
+int goalnet_conv3x3_fwd_split(int parts, const void* x_pads, const void* ws, const float* bias, int relu, float* y,
+                              int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream);
+size_t goalnet_conv3x3_wgrad_split_ws_bytes(int parts, int N, int H, int W, int Cin, int Cout);
+int goalnet_conv3x3_wgrad_split(int parts, const void* x_pads, const void* dy_pads, float* dw, void* ws, size_t ws_bytes,
+                                int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream);
+int goalnet_linear_split_ok(int parts, int M, int64_t K, int J);
+size_t goalnet_linear_fwd_split_ws_bytes(int parts, int M, int64_t K, int J);
+int goalnet_linear_fwd_split(int parts, const void* xs, const void* ws_parts, const float* bias, int relu, const float* dropmask, int64_t ldmask,
+                             float* y, int64_t ldy, float* mult_out, int64_t ldmult, int M, int64_t K, int J, void* ws, size_t ws_bytes,
+                             const float* oscale, void* stream);
+int goalnet_linear_bwd_dx_split(int parts, const void* dys, const void* ws_parts, float* dx, int64_t lddx, int M, int64_t K, int J,
+                                const float* oscale, void* stream);
+int goalnet_linear_bwd_dw_split(int parts, const void* dys, const void* xs, float* dw, int M, int64_t K, int J, const float* oscale, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
                                float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream);
 /* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */

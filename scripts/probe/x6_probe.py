@@ -14,7 +14,7 @@ torch.manual_seed(3)
 
 
 def split_w(w, cout, cin):
-    return ops.split3_rows(w, torch.empty(cout * 9 * 3 * cin, dtype=torch.bfloat16, device=dev), cout * 9, cin)
+    return ops.split_rows(3, w, torch.empty(cout * 9 * 3 * cin, dtype=torch.bfloat16, device=dev), cout * 9, cin)
 
 
 def run_linear(m, k, j):
@@ -27,14 +27,14 @@ def run_linear(m, k, j):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(16)]
     x3 = torch.empty(m * 3 * k, dtype=torch.bfloat16, device=dev)
     w3 = torch.empty(j * 3 * k, dtype=torch.bfloat16, device=dev)
-    dy3 = ops.split3_rows(dy, torch.empty(m * 3 * j, dtype=torch.bfloat16, device=dev), m, j)
+    dy3 = ops.split_rows(3, dy, torch.empty(m * 3 * j, dtype=torch.bfloat16, device=dev), m, j)
     y = torch.empty(m, j, device=dev); dx = torch.empty(m, k, device=dev); dw = torch.empty(j, k, device=dev)
     for rep in range(2):
-        ev[0].record(); ops.split3_rows(x, x3, m, k, scale=sc, shift=sh, bnC=512)
-        ev[1].record(); ops.split3_rows(w, w3, j, k)
-        ev[2].record(); ops.linear_fwd_x6(x3, w3, b, y, m, k, j, relu=True)
-        ev[3].record(); ops.linear_bwd_dx_x6(dy3, w3, dx, m, k, j)
-        ev[4].record(); ops.linear_bwd_dw_x6(dy3, x3, dw, m, k, j)
+        ev[0].record(); ops.split_rows(3, x, x3, m, k, scale=sc, shift=sh, bnC=512)
+        ev[1].record(); ops.split_rows(3, w, w3, j, k)
+        ev[2].record(); ops.linear_fwd_split(3, x3, w3, b, y, m, k, j, relu=True)
+        ev[3].record(); ops.linear_bwd_dx_split(3, dy3, w3, dx, m, k, j)
+        ev[4].record(); ops.linear_bwd_dw_split(3, dy3, x3, dw, m, k, j)
         ev[5].record()
         y32 = torch.empty(m, j, device=dev); ops.linear_fwd(x, w, b, y32, relu=True, scale=sc, shift=sh, bnC=512)
         ev[6].record(); dx32 = torch.empty(m, k, device=dev); ops.linear_bwd_dx(dy, w, dx32)
@@ -57,20 +57,20 @@ def run(n, h, w, cin, cout, check):
     _, xp3 = ops.padded_bf16_alloc(n, h, w, 3 * cin, dev)
     _, dyp3 = ops.padded_bf16_alloc(n, h, w, 3 * cout, dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
-    ev[0].record(); ops.split3_padded(x, sc, sh, xp3, n, h, w, cin)
+    ev[0].record(); ops.split_padded(3, x, sc, sh, xp3, n, h, w, cin)
     ev[1].record(); w3 = split_w(wt, cout, cin)
     y6 = torch.empty(n, h, w, cout, device=dev)
-    ops.conv3x3_fwd_x6(xp3, w3, b, True, y6, n, h, w, cin, cout)              # warm-up
-    ev[2].record(); ops.conv3x3_fwd_x6(xp3, w3, b, True, y6, n, h, w, cin, cout)
+    ops.conv3x3_fwd_split(3, xp3, w3, b, True, y6, n, h, w, cin, cout)              # warm-up
+    ev[2].record(); ops.conv3x3_fwd_split(3, xp3, w3, b, True, y6, n, h, w, cin, cout)
     ev[3].record()
     y32 = torch.empty(n, h, w, cout, device=dev)
     ops.conv3x3_fwd(x, sc, sh, wt, b, True, y32, n, h, w, cin, cout)
     ev[4].record(); ops.conv3x3_fwd(x, sc, sh, wt, b, True, y32, n, h, w, cin, cout)
-    ev[5].record(); ops.split3_padded(dy, None, None, dyp3, n, h, w, cout)
+    ev[5].record(); ops.split_padded(3, dy, None, None, dyp3, n, h, w, cout)
     ev[6].record()
     dw6 = torch.empty(cout * 9 * cin, device=dev)
-    ops.conv3x3_wgrad_x6(xp3, dyp3, dw6, n, h, w, cin, cout)
-    ev[7].record(); ops.conv3x3_wgrad_x6(xp3, dyp3, dw6, n, h, w, cin, cout)
+    ops.conv3x3_wgrad_split(3, xp3, dyp3, dw6, n, h, w, cin, cout)
+    ev[7].record(); ops.conv3x3_wgrad_split(3, xp3, dyp3, dw6, n, h, w, cin, cout)
     ev[8].record()
     dw32 = torch.empty(cout * 9 * cin, device=dev)
     ops.conv3x3_wgrad(x, sc, sh, dy, dw32, n, h, w, cin, cout)
