@@ -697,7 +697,11 @@ class AVM(nn.Module):
             w2s, aw = self._split_w(P("visbl.conv2.weight"), 256 * 9, 64)
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd_split, self._parts,
                         x1s, w2s, P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256, self._osc(ax, aw))
-            del x1s, w2s                             # conv2's weight gradient stays on the fp32 kernel (3 output tiles: no gain)
+            # conv2's weight gradient (3 output tiles of 256 x 256): 12.9 + 2.6 ms (split of dy2) against the fp32 kernel's 13.9 with six
+            # segments — no gain; with three (fp16x3) 6.5 + 3.3 against 14-20: taken
+            if save and self._parts == 2 and os.environ.get("GOALNET_X3_WGRAD2", "1") != "0":
+                ctx.update(x1s=x1s, x1s_amax=ax, x1s_gen=self._padgen["x1s"])
+            del x1s, w2s
         else:
             self._timed("conv_fwd", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_fwd,
                         p1, st1[2], st1[3], P("visbl.conv2.weight"), P("visbl.conv2.bias"), True, y2, n, hp1, wp1, 64, 256)
@@ -1025,6 +1029,13 @@ class AVM(nn.Module):
             dyp2 = dy2
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
                                          ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
+        elif "x1s" in ctx:
+            if ctx["x1s_gen"] != self._padgen["x1s"]:
+                raise RuntimeError("precision='fp16x3': a second training-mode forward overwrote the saved split operands before backward ran")
+            dys2, ady2 = self._split_act("dy2s", dy2, None, None, n, hp1, wp1, 256)
+            osc_w2 = self._osc(ady2, ctx["x1s_amax"])
+            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_split, self._parts,
+                                         ctx["x1s"], dys2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256, osc_w2), dys2)
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
                                          ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
@@ -1036,6 +1047,12 @@ class AVM(nn.Module):
             wtb = ops.cast_bf16(wt, torch.empty(wt.shape, dtype=self._h16, device=dev))
             self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_bf16p,
                         dyp2, wtb, None, False, dbn1, n, hp1, wp1, 256, 64)
+        elif "x1s" in ctx and os.environ.get("GOALNET_X3_DGRAD2", "1") != "0":
+            # fp16x3: the split gradient is there already (weight gradient above); 128 x 64 tile, three segments
+            wts2, awt2 = self._split_w(wt, 64 * 9, 256)
+            self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd_split, self._parts,
+                        dys2, wts2, None, False, dbn1, n, hp1, wp1, 256, 64, self._osc(ady2, awt2))
+            del wts2
         else:
             self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
                         dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)

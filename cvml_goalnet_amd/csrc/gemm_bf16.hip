@@ -361,6 +361,7 @@ __device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&a
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
     const int r = lane & 31, h = lane >> 5;
+    const float osc = ep.oscale ? ep.oscale[1] : 1.f;              // split operands in scaled fp16 (csrc/split3.hip); 1 otherwise
 #pragma unroll
     for (int fn = 0; fn < 2; ++fn) {
         const int col = tn * 64 + fn * 32 + r;
@@ -373,7 +374,7 @@ __device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&a
             if (!(colok && row < ep.rows)) continue;
             const float v = acc[fn][e];
             if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
-            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v + bv, lo);
+            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v * osc + bv, lo);
             else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
         }
     }
@@ -571,7 +572,69 @@ unsigned grid1d(int64_t n) {
     return (unsigned)b;
 }
 
+// ---- split operands (csrc/split3.hip) on the 128 x 64 tile: conv2's data gradient (256 -> 64 channels). Tap-major K order over
+// NSEG x segC virtual channels per tap; virtual 64-channel chunk c reads part (segmap >> 4 (c % NSEG)) & 15 of chunk c / NSEG.
+template <int NSEG>
+__device__ __forceinline__ void seg_tap_channel(int kt, int segC, unsigned segmap, int& tap, int& ci) {
+    const int cpt = NSEG * segC / BKH;                       // virtual chunks per tap
+    tap = kt / cpt;
+    const int chunk = kt - tap * cpt, cc = chunk / NSEG, seg = chunk - NSEG * cc;
+    ci = (int)((segmap >> (4 * seg)) & 15u) * segC + cc * BKH;
+}
+template <int NSEG>
+struct KCLoaderHS : KCLoaderH {
+    struct P { const __hip_bfloat16* x; int64_t ld; int rows; int convC; int segC; unsigned segmap; };   // rows of 9 x convC stored values
+    int convC, segC;
+    unsigned segmap;
+    __device__ KCLoaderHS(const P& p, int row0, int tid, int tile_rows = BM)
+        : KCLoaderH(KCLoaderH::P{p.x, p.ld, p.rows}, row0, tid, tile_rows), convC(p.convC), segC(p.segC), segmap(p.segmap) {}
+    __device__ __forceinline__ void issue(int kt, char* l) const {
+        int tap, ci;
+        seg_tap_channel<NSEG>(kt, segC, segmap, tap, ci);
+        const unsigned koff = (unsigned)((tap * convC + ci) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (wave * 4 + i < npieces) dma16(rx, l + (wave * 4 + i) * 8 * ROWB, voff[i], koff);
+    }
+};
+template <int NSEG>
+struct ConvAPadLoaderHS : ConvAPadLoaderH {
+    struct P { const __hip_bfloat16* x; int H, W, C; int64_t M; int segC; unsigned segmap; };            // C = stored channels per pixel
+    int segC;
+    unsigned segmap;
+    __device__ ConvAPadLoaderHS(const P& p, int row0, int tid)
+        : ConvAPadLoaderH(ConvAPadLoaderH::P{p.x, p.H, p.W, p.C, p.M}, row0, tid), segC(p.segC), segmap(p.segmap) {}
+    __device__ __forceinline__ void issue(int kt, char* l) const {
+        int tap, ci;
+        seg_tap_channel<NSEG>(kt, segC, segmap, tap, ci);
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const unsigned s0 = (unsigned)(((kh * Wp2 + kw) * C + ci) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rx, l + (wave * 4 + i) * 8 * ROWB, voff[i], s0);
+    }
+};
+
 }  // namespace
+
+namespace goalnet {
+// conv 3x3 (forward form; the data gradient of a layer with <= 64 input channels) on split operands, 128 x 64 tile, fp32 result.
+// parts = 3: bf16 triples, six segments; parts = 2: scaled fp16 pairs, three segments (ep.oscale)
+int launch_conv_split_h64(const char* name, int parts, const __hip_bfloat16* x_pads, int H, int W, int Cin, int64_t M,
+                          const __hip_bfloat16* ws, int Cout, const EpiP& ep, hipStream_t st) {
+    if (parts == 3) {
+        typedef ConvAPadLoaderHS<6> AL;
+        typedef KCLoaderHS<6> BL;
+        AL::P ap{x_pads, H, W, 3 * Cin, M, Cin, 0x010201u};
+        BL::P bp{ws, (int64_t)9 * 3 * Cin, Cout, 3 * Cin, Cin, 0x001021u};
+        return launch_gemm_h<AL, BL, true>(name, ap, bp, ep, M, Cout, 9 * 6 * Cin / BKH, 1, 0, false, st);
+    }
+    typedef ConvAPadLoaderHS<3> AL;
+    typedef KCLoaderHS<3> BL;
+    AL::P ap{x_pads, H, W, 2 * Cin, M, Cin, 0x010u};
+    BL::P bp{ws, (int64_t)9 * 2 * Cin, Cout, 2 * Cin, Cin, 0x001u};
+    return launch_gemm_h<AL, BL, true>(name, ap, bp, ep, M, Cout, 9 * 3 * Cin / BKH, 1, 0, true, st);
+}
+}  // namespace goalnet
 
 extern "C" {
 

@@ -22,6 +22,8 @@ using namespace goalnet;
 namespace goalnet {
 int launch_conv_split_256(const char* name, int parts, const __hip_bfloat16* x_pads, int H, int W, int Cin, int64_t M,
                           const __hip_bfloat16* ws, int Cout, const EpiP& ep, hipStream_t st);
+int launch_conv_split_h64(const char* name, int parts, const __hip_bfloat16* x_pads, int H, int W, int Cin, int64_t M,
+                          const __hip_bfloat16* ws, int Cout, const EpiP& ep, hipStream_t st);
 int wgrad_split_splits_256(int parts, int64_t Mp, int Cin, int Cout);
 int launch_wgrad_split_256(const char* name, int parts, const __hip_bfloat16* x_pads, const __hip_bfloat16* dy_pads, int Wp2, int Cin,
                            int Cout, int64_t Mp, float* slabs, int nsplit, hipStream_t st);
@@ -259,6 +261,9 @@ int goalnet_conv3x3_fwd_split(int parts, const void* x_pads, const void* ws, con
                "conv3x3_fwd_split: frame too large for one tile window");
     EpiP ep{EPI_BIAS_RELU, y, Cout, (int)M, Cout, bias, relu, nullptr, 0, nullptr, 0, 0};
     ep.oscale = parts == 2 ? oscale : nullptr;
+    // <= 64 output channels (a data gradient into 64 channels): the 128 x 64 tile; a 256-wide tile would be three quarters empty
+    if (Cout <= 64) return launch_conv_split_h64("conv3x3_fwd_split(128x64)", parts, (const __hip_bfloat16*)x_pads, H, W, Cin, M,
+                                                 (const __hip_bfloat16*)ws, Cout, ep, (hipStream_t)stream);
     return launch_conv_split_256("conv3x3_fwd_split", parts, (const __hip_bfloat16*)x_pads, H, W, Cin, M, (const __hip_bfloat16*)ws, Cout, ep,
                                  (hipStream_t)stream);
 }

@@ -845,7 +845,8 @@ def test_split_is_exact_and_lays_the_parts_out_side_by_side(parts):
 
 @pytest.mark.parametrize("parts", [3, 2])
 @pytest.mark.parametrize("n,h,w,cin,cout,bias,relu", [(2, 9, 11, 64, 256, True, True), (3, 24, 24, 256, 512, True, True),
-                                                      (1, 13, 40, 128, 72, False, False), (5, 37, 29, 64, 264, True, False)])
+                                                      (1, 13, 40, 128, 72, False, False), (5, 37, 29, 64, 264, True, False),
+                                                      (3, 21, 19, 256, 64, False, False)])      # 64 output channels: the 128 x 64 tile
 def test_conv3x3_split_forward_data_gradient_and_weight_gradient_vs_fp64(n, h, w, cin, cout, bias, relu, parts):
     """goalnet_conv3x3_fwd_split / goalnet_conv3x3_wgrad_split against fp64 on the UNROUNDED fp32 operands, whole and ragged tiles, with
     the fp32 engine's kernels beside them: the split-operand results must be fp32-grade — within 6e-6 of the output scale (measured
