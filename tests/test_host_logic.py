@@ -271,3 +271,26 @@ def test_fused_adam_optimizer_can_be_created_before_the_first_forward():
         Adam(m.parameters(), lr=0.001).step()            # no model given
     with pytest.raises(ValueError):
         Adam(m.parameters(), lr=-1.0, model=m)
+
+
+def test_the_fp32_gemm_kernels_keep_their_accumulators_out_of_scratch(tmp_path):
+    """Build-level guard for the headline kernels (csrc/gemm_f32.hip): the conv forward instantiation uses no scratch at all and no
+    gemm_f32_kernel instantiation more than 64 bytes per lane (the one-stage forms are capped at 128 VGPRs for four blocks per CU and
+    spill 2-11 registers at their tile boundaries: 8-44 bytes). Round 3 found out why this is worth 20 s: one more conditional load
+    in `epi_apply` kept the epilogue's store loop from unrolling, the accumulators were indexed dynamically and moved to scratch (352 B
+    per lane), and the fp32 conv forward fell from 0.85 to 0.54 of peak (357 GB of traffic per launch) with every parity test green."""
+    import re
+    import subprocess
+    import __graft_entry__ as ge
+    src = os.path.join(ge.CSRC, "gemm_f32.hip")
+    r = subprocess.run([ge.HIPCC, *ge.FLAGS, "-I" + os.path.join(ge.ROOT, "include"), "--cuda-device-only", "-c", src, "-o", str(tmp_path / "g.o"),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) and len(names) >= 10
+    gemm = [(n, s) for n, s in zip(names, scratch) if "gemm_f32_kernel" in n]
+    bad = [(n, s) for n, s in gemm if s > 64]
+    assert not bad, f"fp32 GEMM kernels with their accumulators in scratch: {bad}"
+    fwd = [s for n, s in gemm if "ConvALoaderILb1EEENS_8KCLoaderILb0EEELb0ELi1" in n]
+    assert fwd == [0], f"the fp32 conv forward kernel uses scratch: {fwd}"
