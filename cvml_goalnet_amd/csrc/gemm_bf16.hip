@@ -361,7 +361,7 @@ __device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&a
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     const int mode = ep.slab_stride > 0 ? EPI_RAW : ep.mode;
     const int r = lane & 31, h = lane >> 5;
-    const float osc = ep.oscale ? ep.oscale[1] : 1.f;              // split operands in scaled fp16 (csrc/split3.hip); 1 otherwise
+    const int osc = ep.oscale ? *ep.oscale : 0;                    // split operands in scaled fp16 (csrc/split3.hip): exponent to add; 0 otherwise
 #pragma unroll
     for (int fn = 0; fn < 2; ++fn) {
         const int col = tn * 64 + fn * 32 + r;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void store_acc_h_n64(const EpiP& ep, const f32x16 (&a
             if (!(colok && row < ep.rows)) continue;
             const float v = acc[fn][e];
             if (mode == EPI_RAW) outp[row * ep.ld + col] = v;
-            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(v * osc + bv, lo);
+            else if (mode == EPI_BIAS_RELU) outp[row * ep.ld + col] = fmaxf(ldexpf(v, osc) + bv, lo);
             else outp[row * ep.ld + col] = epi_apply(ep, v, row, col);
         }
     }

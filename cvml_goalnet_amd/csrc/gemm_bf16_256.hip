@@ -366,10 +366,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // WALK: the block goes on to the virtual blocks L + gridDim.x, ... (launch_256_t launches one block per CU for these roles);
     // the other roles run one tile per block and compile without the hand-over (no register pressure from it, no spills).
     constexpr bool WALK = walks_tiles(ROLE);
-    // fp16x3 (three segments): the operands were scaled by powers of two, oscale = {their product, its inverse} (EpiP)
+    // fp16x3 (three segments): the operands were scaled by powers of two; *ep.oscale = the exponent that undoes both (ldexpf: exact, and
+    // no product of scales that could overflow). The bias then cannot ride in the accumulators: it is added after the unscaling (LATE_BIAS).
     constexpr bool OSC = AL::NSEGS == 3;
-    float osc_mul = 1.f, osc_inv = 1.f;
-    if constexpr (OSC) { if (ep.oscale) { osc_mul = ep.oscale[0]; osc_inv = ep.oscale[1]; } }
+    constexpr bool LATE_BIAS = OSC && ROLE == 0;
+    int osc_k = 0;
+    if constexpr (OSC) { if (ep.oscale) osc_k = *ep.oscale; }
     extern __shared__ __attribute__((aligned(16))) char lds[];          // [2 K-tiles][A0, A1, B0, B1][128 rows][128 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,11 +412,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     if constexpr (ROLE == 0) {                                                                              \
         if constexpr (SWAP) {                                                                               \
             bias_t = 0.f;                                                                                   \
-            if (ep.bias && tid < T && tn * T + tid < ep.cols) bias_t = ep.bias[tn * T + tid] * osc_mul;     \
+            if (ep.bias && tid < T && tn * T + tid < ep.cols) bias_t = ep.bias[tn * T + tid];               \
         } else {                                                                                            \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                 \
                 const int colj = tn * T + wc * 64 + j * 32 + (lane & 31);                                   \
-                bias_col[j] = ep.bias && colj < ep.cols ? ep.bias[colj] * osc_mul : 0.f;                    \
+                bias_col[j] = ep.bias && colj < ep.cols ? ep.bias[colj] : 0.f;                              \
             }                                                                                               \
         }                                                                                                   \
     }
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (ROLE == 0) b4 = *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5)]);
+                if constexpr (ROLE == 0 && !LATE_BIAS) b4 = *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5)]);
                 bj[4 * g] = b4.x; bj[4 * g + 1] = b4.y; bj[4 * g + 2] = b4.z; bj[4 * g + 3] = b4.w;
             }
 #pragma unroll
@@ -559,10 +561,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     const int r = lane & 31, hh = lane >> 5;
     // what is left to do per value: ROLE 0 (conv forward) clamps at 0 when ReLU is on (its bias is already in); the
     // other roles store the accumulator as it is (their callers pass no bias and no ReLU)
-    auto fin = [&](float v) -> float {
-        if constexpr (OSC) v *= osc_inv;
+    auto fin = [&](float v, float b = 0.f) -> float {
+        if constexpr (OSC) v = ldexpf(v, osc_k);
+        if constexpr (LATE_BIAS) v += b;
         if constexpr (ROLE == 0) return ep.relu ? fmaxf(v, 0.f) : v;
         else return v;
+    };
+    // LATE_BIAS: the four bias values of register group g of acc[.][ni] (this tile's columns are still in bias_lds: the next tile's are
+    // written at the top of the loop, behind a barrier every wave joins after its epilogue)
+    auto bias4 = [&](int ni, int g) -> float4 {
+        if constexpr (LATE_BIAS) return *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + ni * 32 + 8 * g + 4 * (lane >> 5)]);
+        else return make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
     if constexpr (SWAP) {
@@ -582,10 +591,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
                         unsigned x[2], y[2];
+                        const float4 b0 = bias4(ni, 2 * gp), b1 = bias4(ni, 2 * gp + 1);
+                        const float bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                         for (int d = 0; d < 2; ++d) {
-                            const unsigned p0 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 2 * d]), fin(acc[mi][ni][8 * gp + 2 * d + 1]));
-                            const unsigned p1 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 4 + 2 * d]), fin(acc[mi][ni][8 * gp + 4 + 2 * d + 1]));
+                            const unsigned p0 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 2 * d], bb0[2 * d]), fin(acc[mi][ni][8 * gp + 2 * d + 1], bb0[2 * d + 1]));
+                            const unsigned p1 = pack2_h16<F16>(fin(acc[mi][ni][8 * gp + 4 + 2 * d], bb1[2 * d]), fin(acc[mi][ni][8 * gp + 4 + 2 * d + 1], bb1[2 * d + 1]));
                             // lower lane: (its group 2gp, the upper lane's 2gp); upper lane: (the lower lane's 2gp+1, its 2gp+1)
                             const auto sw = __builtin_amdgcn_permlane32_swap(p0, p1, false, false);
                             x[d] = sw[0]; y[d] = sw[1];
@@ -623,9 +634,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int col = tn * T + (TRB ? ni * 128 + 16 * wc + 8 * (g & 1) + 4 * hh + 64 * (g >> 1) : wc * 64 + ni * 32 + 8 * g + 4 * hh);
+                        const float4 b4 = bias4(ni, g);
                         if (row < ep.rows && col < ep.cols)                                            // cols % 4 == 0
                             *reinterpret_cast<float4*>(outp + row * ep.ld + col) =
-                                make_float4(fin(acc[mi][ni][4 * g]), fin(acc[mi][ni][4 * g + 1]), fin(acc[mi][ni][4 * g + 2]), fin(acc[mi][ni][4 * g + 3]));
+                                make_float4(fin(acc[mi][ni][4 * g], b4.x), fin(acc[mi][ni][4 * g + 1], b4.y), fin(acc[mi][ni][4 * g + 2], b4.z),
+                                            fin(acc[mi][ni][4 * g + 3], b4.w));
                     }
             }
         }
@@ -944,7 +957,7 @@ int launch_linear_fwd_split_256(const char* name, int parts, const __hip_bfloat1
 
 template <int NSEG>
 static int launch_linear_dx_split_t(const char* name, const __hip_bfloat16* dys, const __hip_bfloat16* ws, int M, int64_t K, int J, float* dx,
-                                    int64_t lddx, const float* oscale, hipStream_t st) {
+                                    int64_t lddx, const int* oscale, hipStream_t st) {
     typedef KCLoader256<64, NSEG> AL;
     typedef MCLoader256T<NSEG> BL;
     typedef SegCfg<NSEG> S;
@@ -957,14 +970,14 @@ static int launch_linear_dx_split_t(const char* name, const __hip_bfloat16* dys,
     return launch_256_t<AL, BL, 4, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, st);
 }
 int launch_linear_dx_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* ws, int M, int64_t K, int J,
-                               float* dx, int64_t lddx, const float* oscale, hipStream_t st) {
+                               float* dx, int64_t lddx, const int* oscale, hipStream_t st) {
     return parts == 3 ? launch_linear_dx_split_t<6>(name, dys, ws, M, K, J, dx, lddx, oscale, st)
                       : launch_linear_dx_split_t<3>(name, dys, ws, M, K, J, dx, lddx, oscale, st);
 }
 
 template <int NSEG>
 static int launch_linear_dw_split_t(const char* name, const __hip_bfloat16* dys, const __hip_bfloat16* xs, int M, int64_t K, int J, float* dw,
-                                    const float* oscale, hipStream_t st) {
+                                    const int* oscale, hipStream_t st) {
     typedef MCLoader256T<NSEG> AL;
     typedef MCLoader256T<NSEG> BL;
     typedef SegCfg<NSEG> S;
@@ -977,7 +990,7 @@ static int launch_linear_dw_split_t(const char* name, const __hip_bfloat16* dys,
     return launch_256_t<AL, BL, 5, S::F16>(name, ap, bp, ep, tiles_m, tiles_n, 1, 1, ktiles, ktiles, st);
 }
 int launch_linear_dw_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* xs, int M, int64_t K, int J,
-                               float* dw, const float* oscale, hipStream_t st) {
+                               float* dw, const int* oscale, hipStream_t st) {
     return parts == 3 ? launch_linear_dw_split_t<6>(name, dys, xs, M, K, J, dw, oscale, st)
                       : launch_linear_dw_split_t<3>(name, dys, xs, M, K, J, dw, oscale, st);
 }

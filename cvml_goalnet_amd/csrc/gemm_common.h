@@ -31,12 +31,13 @@ struct EpiP {
     // sums the tile's slabs in split order (the order of splitk_reduce_kernel: same bits) and applies this epilogue (out, ld,
     // bias, relu, mul, mult_out) — no second launch. tile_ctr[] must be zero on entry and is zero again on exit.
     float* slabs; int* tile_ctr;
-    // split operands in fp16 (csrc/split3.hip, "fp16x3"): the GEMM ran on operands scaled by powers of two; oscale[0] = their product,
-    // oscale[1] = its inverse (device memory, written by goalnet_split_scales). Applied to the accumulated value before bias / ReLU by the
-    // kernels that serve those modes ONLY (gemm_bf16_256_kernel, the 128 x 64 tile's store, the split-K reduction kernels) — not by
-    // epi_apply: one more conditional load inside the fp32 GEMM's unrolled store loop kept it from unrolling, its accumulators went to
-    // scratch (352 B per lane) and the fp32 conv forward dropped from 0.85 to 0.54 of peak with 357 GB of "HBM" traffic per launch.
-    const float* oscale = nullptr;
+    // split operands in fp16 (csrc/split3.hip, "fp16x3"): the GEMM ran on operands scaled by powers of two 2^ka, 2^kb; *oscale = -(ka + kb)
+    // (device memory, written by goalnet_split_scales): the accumulated value becomes ldexpf(v, *oscale) — one instruction, exact, and no
+    // intermediate product of scales that could overflow — BEFORE bias / ReLU. Applied by the kernels that serve those modes ONLY
+    // (gemm_bf16_256_kernel, the 128 x 64 tile's store, the split-K reduction kernels) — not by epi_apply: one more conditional load inside
+    // the fp32 GEMM's unrolled store loop kept it from unrolling, its accumulators went to scratch (352 B per lane) and the fp32 conv
+    // forward dropped from 0.85 to 0.54 of peak with 357 GB of "HBM" traffic per launch.
+    const int* oscale = nullptr;
 };
 
 __device__ __forceinline__ float epi_apply(const EpiP& e, float v, int64_t row, int col) {

@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
             const float4 b = *reinterpret_cast<const float4*>(s + (int64_t)k * slab_stride);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        if (ep.oscale) { const float inv = ep.oscale[1]; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv; }    // split operands in scaled fp16
+        if (ep.oscale) { const int k = *ep.oscale; a.x = ldexpf(a.x, k); a.y = ldexpf(a.y, k); a.z = ldexpf(a.z, k); a.w = ldexpf(a.w, k); }   // scaled fp16 operands
         if (ep.corr_u) {       // fp32 conv weight gradient: what the padding taps accumulated through the BatchNorm shift
             const int tap = col / ep.corr_C, ci = col - tap * ep.corr_C;
             const float u = ep.corr_u[row * 9 + tap];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* sl
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         a.x = row16_sum(a.x); a.y = row16_sum(a.y); a.z = row16_sum(a.z); a.w = row16_sum(a.w);
-        if (ep.oscale) { const float inv = ep.oscale[1]; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv; }
+        if (ep.oscale) { const int k = *ep.oscale; a.x = ldexpf(a.x, k); a.y = ldexpf(a.y, k); a.z = ldexpf(a.z, k); a.w = ldexpf(a.w, k); }
         if (ep.corr_u) {       // as in splitk_reduce_kernel
             const int tap = col / ep.corr_C, ci = col - tap * ep.corr_C;
             const float u = ep.corr_u[row * 9 + tap];

@@ -11,7 +11,8 @@
 // precision = "fp16x3" is the same scheme with TWO fp16 parts of the value scaled by a power of two: hi = fp16(v s), mid = fp16(v s - hi)
 // (11 + 11 significand bits; s puts the tensor's largest magnitude into [2^14, 2^15), goalnet_absmax -> scale_of_amax) and the THREE
 // products hi hi, hi mid, mid hi (the dropped mid mid is 2^-22 |a b|): half the MFMA work of bf16x6. The GEMM epilogues undo the two
-// scales (EpiP::oscale from goalnet_split_scales; powers of two: exact).
+// scales with one ldexpf (EpiP::oscale = the exponent from goalnet_split_scales: exact, no intermediate that could overflow); a bias is
+// added after that, not carried in the accumulators.
 //
 // This file: the split passes (activations into the zero-padded layout with the BatchNorm affine applied, weights and linear5's
 // operands row by row), the magnitude pass of fp16x3 and the C-ABI entry points. fp32 everywhere else: results, accumulators, bias, ReLU.
@@ -31,9 +32,9 @@ int linear_fwd_split_splits_256(int parts, int M, int64_t K, int J);
 int launch_linear_fwd_split_256(const char* name, int parts, const __hip_bfloat16* xs, const __hip_bfloat16* ws, int M, int64_t K, int J,
                                 float* slabs, int nsplit, hipStream_t st);
 int launch_linear_dx_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* ws, int M, int64_t K, int J,
-                               float* dx, int64_t lddx, const float* oscale, hipStream_t st);
+                               float* dx, int64_t lddx, const int* oscale, hipStream_t st);
 int launch_linear_dw_split_256(const char* name, int parts, const __hip_bfloat16* dys, const __hip_bfloat16* xs, int M, int64_t K, int J,
-                               float* dw, const float* oscale, hipStream_t st);
+                               float* dw, const int* oscale, hipStream_t st);
 }  // namespace goalnet
 
 namespace {
@@ -161,11 +162,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits, m);
 }
 
-// oscale[0] = s_a s_b, oscale[1] = 1 / (s_a s_b): what the GEMM epilogues multiply bias / results with (EpiP::oscale)
-__global__ void split_scales_kernel(const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_b, float* __restrict__ oscale) {
-    const float s = scale_of_amax(*amax_a) * scale_of_amax(*amax_b);
-    oscale[0] = s;
-    oscale[1] = 1.f / s;                   // a power of two: exact
+// *oscale = -(k_a + k_b) with s = 2^k the scales of the two operands: what the GEMM epilogues add to the exponent of their sums
+// (EpiP::oscale; ldexpf — the product of the two scales itself can leave fp32's range, e.g. two tensors of magnitude 1e-20)
+__device__ __forceinline__ int exp_of_amax(unsigned amax_bits) {
+    if (amax_bits == 0u) return 0;
+    int e = (int)(amax_bits >> 23);
+    e = e < 14 ? 14 : e;
+    return 141 - e;                                                    // scale_of_amax = 2^(141 - e)
+}
+__global__ void split_scales_kernel(const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_b, int* __restrict__ oscale) {
+    oscale[0] = -(exp_of_amax(*amax_a) + exp_of_amax(*amax_b));
 }
 
 unsigned grid1d(int64_t n) {
@@ -201,9 +207,9 @@ int goalnet_absmax(const float* x, int64_t ldx, const float* scale, const float*
     return 0;
 }
 
-int goalnet_split_scales(const unsigned* amax_a, const unsigned* amax_b, float* oscale2, void* stream) {
-    GN_REQUIRE(amax_a && amax_b && oscale2, GOALNET_E_NULL, "split_scales: null pointer");
-    hipLaunchKernelGGL(split_scales_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_a, amax_b, oscale2);
+int goalnet_split_scales(const unsigned* amax_a, const unsigned* amax_b, int* oscale, void* stream) {
+    GN_REQUIRE(amax_a && amax_b && oscale, GOALNET_E_NULL, "split_scales: null pointer");
+    hipLaunchKernelGGL(split_scales_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_a, amax_b, oscale);
     GN_LAUNCH_CHECK("split_scales");
     return 0;
 }
@@ -248,7 +254,7 @@ int goalnet_split_rows(int parts, const float* x, int64_t ldx, const float* scal
  * guard pixels in front and behind, as goalnet_conv3x3_fwd_bf16p), ws [Cout][9][parts Cin]. bias nullable; relu 0 / 1. The data
  * gradient is the same call on the split gradient and the split flipped weights. parts = 2: oscale from goalnet_split_scales. */
 int goalnet_conv3x3_fwd_split(int parts, const void* x_pads, const void* ws, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream) {
+                              int N, int H, int W, int Cin, int Cout, const int* oscale, void* stream) {
     GN_PARTS_OK("conv3x3_fwd_split");
     GN_REQUIRE(x_pads && ws && y && (parts == 3 || oscale), GOALNET_E_NULL, "conv3x3_fwd_split: null pointer (parts = 2 needs oscale)");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE, "conv3x3_fwd_split: non-positive dim");
@@ -277,7 +283,7 @@ size_t goalnet_conv3x3_wgrad_split_ws_bytes(int parts, int N, int H, int W, int 
 /* dw[Cout][3][3][Cin] (fp32) = sum over the padded pixel grid of dy[pm][co] * x[pm + shift(tap)][ci], both operands split:
  * x_pads [padded pixels][parts Cin], dy_pads [padded pixels][parts Cout] (zero borders and guards as for goalnet_conv3x3_wgrad_bf16) */
 int goalnet_conv3x3_wgrad_split(int parts, const void* x_pads, const void* dy_pads, float* dw, void* ws, size_t ws_bytes,
-                                int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, const int* oscale, void* stream) {
     GN_PARTS_OK("conv3x3_wgrad_split");
     GN_REQUIRE(x_pads && dy_pads && dw && ws && (parts == 3 || oscale), GOALNET_E_NULL, "conv3x3_wgrad_split: null pointer (parts = 2 needs oscale)");
     GN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, GOALNET_E_SHAPE,
@@ -312,7 +318,7 @@ size_t goalnet_linear_fwd_split_ws_bytes(int parts, int M, int64_t K, int J) {
 
 int goalnet_linear_fwd_split(int parts, const void* xs, const void* wsp, const float* bias, int relu, const float* dropmask, int64_t ldmask,
                              float* y, int64_t ldy, float* mult_out, int64_t ldmult, int M, int64_t K, int J, void* ws, size_t ws_bytes,
-                             const float* oscale, void* stream) {
+                             const int* oscale, void* stream) {
     GN_REQUIRE(xs && wsp && y && ws && (parts == 3 || oscale), GOALNET_E_NULL, "linear_fwd_split: null pointer (parts = 2 needs oscale)");
     GN_REQUIRE(goalnet_linear_split_ok(parts, M, K, J) && ldy % 4 == 0, GOALNET_E_SHAPE, "linear_fwd_split: dims not served (goalnet_linear_split_ok)");
     GN_REQUIRE(aligned16(xs) && aligned16(wsp) && aligned16(y) && aligned16(ws), GOALNET_E_ALIGN, "linear_fwd_split: alignment");
@@ -328,7 +334,7 @@ int goalnet_linear_fwd_split(int parts, const void* xs, const void* wsp, const f
 
 /* dx[m][k] (fp32) = sum_j dy[m][j] w[j][k] from dys [M][parts J] and ws [J][parts K] */
 int goalnet_linear_bwd_dx_split(int parts, const void* dys, const void* wsp, float* dx, int64_t lddx, int M, int64_t K, int J,
-                                const float* oscale, void* stream) {
+                                const int* oscale, void* stream) {
     GN_REQUIRE(dys && wsp && dx && (parts == 3 || oscale), GOALNET_E_NULL, "linear_bwd_dx_split: null pointer (parts = 2 needs oscale)");
     GN_REQUIRE(goalnet_linear_split_ok(parts, M, K, J) && lddx % 4 == 0 && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dx_split: dims not served");
     GN_REQUIRE(aligned16(dys) && aligned16(wsp) && aligned16(dx), GOALNET_E_ALIGN, "linear_bwd_dx_split: alignment");
@@ -337,7 +343,7 @@ int goalnet_linear_bwd_dx_split(int parts, const void* dys, const void* wsp, flo
 }
 
 /* dw[j][k] (fp32) = sum_m dy[m][j] x[m][k] from dys [M][parts J] and xs [M][parts K] */
-int goalnet_linear_bwd_dw_split(int parts, const void* dys, const void* xs, float* dw, int M, int64_t K, int J, const float* oscale, void* stream) {
+int goalnet_linear_bwd_dw_split(int parts, const void* dys, const void* xs, float* dw, int M, int64_t K, int J, const int* oscale, void* stream) {
     GN_REQUIRE(dys && xs && dw && (parts == 3 || oscale), GOALNET_E_NULL, "linear_bwd_dw_split: null pointer (parts = 2 needs oscale)");
     GN_REQUIRE(goalnet_linear_split_ok(parts, M, K, J) && K < (1ll << 31) - 256, GOALNET_E_SHAPE, "linear_bwd_dw_split: dims not served");
     GN_REQUIRE(aligned16(dys) && aligned16(xs) && aligned16(dw), GOALNET_E_ALIGN, "linear_bwd_dw_split: alignment");

@@ -431,8 +431,8 @@ def absmax(x, amax, rows, C, scale=None, shift=None, bnC=0):
 
 
 def split_scales(amax_a, amax_b, oscale=None):
-    """oscale = (s_a s_b, 1 / (s_a s_b)) on the device, from the two operands' magnitude words"""
-    oscale = torch.empty(2, dtype=F32, device=amax_a.device) if oscale is None else oscale
+    """oscale = the exponent (int32 word on the device) the GEMM epilogue adds to undo the two operands' power-of-two scales"""
+    oscale = torch.empty(1, dtype=torch.int32, device=amax_a.device) if oscale is None else oscale
     _chk(amax_a, amax_b, oscale)
     check(lib().goalnet_split_scales(amax_a.data_ptr(), amax_b.data_ptr(), oscale.data_ptr(), _s()), "split_scales")
     return oscale

@@ -210,11 +210,11 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
  * backward, /root/reference/main.py:192) with fp32-grade products on the 16-bit MFMA. `parts` = 3: an fp32 operand value is stored as
  * three bf16 values hi + mid + lo (exact), six partial products per product; `parts` = 2: as two fp16 values hi + mid of the value
  * scaled by a power of two (22 significand bits; the scale puts the tensor's largest magnitude, goalnet_absmax, into [2^14, 2^15)),
- * three partial products per product, and the epilogues undo the scales (`oscale` from goalnet_split_scales; NULL for parts = 3).
+ * three partial products per product, and the epilogues undo the scales (`oscale` = one exponent from goalnet_split_scales; NULL for parts = 3).
  * The parts lie side by side along the channel / row axis; a GEMM is ONE launch of the 16-bit kernel with the partial products as
  * K-segments, fp32 accumulation, fp32 result.
  *   absmax        : atomic max of the bit pattern of |x[r][c] * scale[c % bnC] + shift[c % bnC]| into *amax_bits (zeroed by the caller)
- *   split_scales  : oscale2[0] = s_a s_b, oscale2[1] = 1 / (s_a s_b) from the two operands' amax words
+ *   split_scales  : *oscale = -(k_a + k_b), the exponent the GEMM epilogue adds (ldexpf) to undo the operands' scales 2^k_a, 2^k_b
  *   split_padded  : x fp32 [N][H][W][C] (optional per-channel affine = the BatchNorm, applied in fp32) -> zero-padded
  *                   [N][H+2][W+2][parts C] 16-bit, interior only (borders / guards zeroed once by the caller, layout of to_bf16_padded)
  *   split_rows    : x fp32 [rows][C] (row stride ldx; optional affine per column c with channel c % bnC) -> [rows][parts C] 16-bit
@@ -225,24 +225,24 @@ int goalnet_conv3x3_wgrad_bf16(const void* x_pad, const void* dy_pad, float* dw,
  *                   dys [M][parts J]; goalnet_linear_split_ok says whether the dims are served (256 x 256 tile only) */
 int goalnet_absmax(const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, int64_t rows, int64_t C,
                    unsigned* amax_bits, void* stream);
-int goalnet_split_scales(const unsigned* amax_a, const unsigned* amax_b, float* oscale2, void* stream);
+int goalnet_split_scales(const unsigned* amax_a, const unsigned* amax_b, int* oscale, void* stream);
 int goalnet_split_padded(int parts, const float* x, const float* scale, const float* shift, const unsigned* amax_bits, void* y_pads,
                          int N, int H, int W, int C, void* stream);
 int goalnet_split_rows(int parts, const float* x, int64_t ldx, const float* scale, const float* shift, int bnC, const unsigned* amax_bits,
                        void* ys, int64_t rows, int64_t C, void* stream);
 int goalnet_conv3x3_fwd_split(int parts, const void* x_pads, const void* ws, const float* bias, int relu, float* y,
-                              int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream);
+                              int N, int H, int W, int Cin, int Cout, const int* oscale, void* stream);
 size_t goalnet_conv3x3_wgrad_split_ws_bytes(int parts, int N, int H, int W, int Cin, int Cout);
 int goalnet_conv3x3_wgrad_split(int parts, const void* x_pads, const void* dy_pads, float* dw, void* ws, size_t ws_bytes,
-                                int N, int H, int W, int Cin, int Cout, const float* oscale, void* stream);
+                                int N, int H, int W, int Cin, int Cout, const int* oscale, void* stream);
 int goalnet_linear_split_ok(int parts, int M, int64_t K, int J);
 size_t goalnet_linear_fwd_split_ws_bytes(int parts, int M, int64_t K, int J);
 int goalnet_linear_fwd_split(int parts, const void* xs, const void* ws_parts, const float* bias, int relu, const float* dropmask, int64_t ldmask,
                              float* y, int64_t ldy, float* mult_out, int64_t ldmult, int M, int64_t K, int J, void* ws, size_t ws_bytes,
-                             const float* oscale, void* stream);
+                             const int* oscale, void* stream);
 int goalnet_linear_bwd_dx_split(int parts, const void* dys, const void* ws_parts, float* dx, int64_t lddx, int M, int64_t K, int J,
-                                const float* oscale, void* stream);
-int goalnet_linear_bwd_dw_split(int parts, const void* dys, const void* xs, float* dw, int M, int64_t K, int J, const float* oscale, void* stream);
+                                const int* oscale, void* stream);
+int goalnet_linear_bwd_dw_split(int parts, const void* dys, const void* xs, float* dw, int M, int64_t K, int J, const int* oscale, void* stream);
 int goalnet_linear_bwd_dx_bf16(const void* dy_bf16, int64_t lddy, const void* w_bf16, const float* mult, int64_t ldmult,
                                float* dx, int64_t lddx, int M, int64_t K, int J, int f16, void* stream);
 /* dx as bf16 (no mult), same contract as goalnet_conv3x3_fwd_bf16p_o16 */

@@ -933,3 +933,30 @@ def test_linear5_on_split_operands_forward_dx_dw_vs_fp64(parts):
     dw = torch.full((j, k), float("nan"), device=DEV)
     ops.linear_bwd_dw_split(parts, dys, xs, dw, m, k, j, oscale=osc(ady, ax))
     close(f"linear_bwd_dw_split[{parts}] vs fp64", dw, dy.double().t() @ xh, rtol=6e-6)
+
+
+@pytest.mark.parametrize("magnitude", [0.0, 1e-30, 1e-12, 1.0, 3e4, 1e30])
+def test_fp16x3_scaling_keeps_any_fp32_magnitude_in_range(magnitude):
+    """parts = 2: whatever the magnitude of an operand tensor (zero, 1e-30 .. 1e30), its power-of-two scale puts the largest value into
+    [2^14, 2^15) — inside binary16 — and the GEMM's epilogue undoes both scales exactly: the convolution of x * magnitude equals magnitude
+    times the convolution of x to fp32-grade accuracy (6e-6 of the output scale), and an all-zero operand gives exact zeros."""
+    n, h, w, cin, cout = 2, 9, 11, 64, 256
+    x = rnd(n, h, w, cin, seed=400) * magnitude
+    wt = rnd(cout, 3, 3, cin, seed=401) * 0.05
+    xd, wd = x.to(DEV), wt.to(DEV).view(-1)
+    ax, aw = _amax_word(xd, n * h * w, cin), _amax_word(wd, cout * 9, cin)
+    if magnitude > 0:
+        assert 2 ** 14 <= x.abs().max().item() * _scale_of(ax) < 2 ** 15
+    else:
+        assert int(ax.item()) == 0
+    _, xps = ops.padded_bf16_alloc(n, h, w, 2 * cin, DEV, dtype=torch.float16)
+    ops.split_padded(2, xd, None, None, xps, n, h, w, cin, amax=ax)
+    assert torch.isfinite(xps.float()).all()
+    wsp = ops.split_rows(2, wd, torch.empty(cout * 9 * 2 * cin, dtype=torch.float16, device=DEV), cout * 9, cin, amax=aw)
+    y = torch.full((n, h, w, cout), float("nan"), device=DEV)
+    ops.conv3x3_fwd_split(2, xps, wsp, None, False, y, n, h, w, cin, cout, oscale=ops.split_scales(ax, aw))
+    ref = nhwc(F.conv2d(nchw(x.double()), nchw(wt.double()), None, padding=1))
+    if magnitude == 0.0:
+        assert not y.any()
+    else:
+        close(f"conv of x * {magnitude:g} on scaled fp16 pairs vs fp64", y, ref, rtol=6e-6)
