@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 A="--steps 3 --warmup 2 --no-cpu-baseline --no-native40 --no-second-path --no-live-traffic --dtype bf16"
-for v in ${VARIANTS:-new old new2}; do
+for v in ${VARIANTS:-new new2}; do   # add "old" with OLD_LIB=<variant .so under csrc/build> for an A/B against another build
   unset GOALNET_LIB_PATH
   if [ $v = old ]; then export GOALNET_LIB_PATH=$R/cvml_goalnet_amd/csrc/build/${OLD_LIB:-libgoalnet_noswap.so}; fi
   rm -rf /tmp/rt$v
