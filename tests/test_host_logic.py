@@ -294,3 +294,38 @@ def test_the_fp32_gemm_kernels_keep_their_accumulators_out_of_scratch(tmp_path):
     assert not bad, f"fp32 GEMM kernels with their accumulators in scratch: {bad}"
     fwd = [s for n, s in gemm if "ConvALoaderILb1EEENS_8KCLoaderILb0EEELb0ELi1" in n]
     assert fwd == [0], f"the fp32 conv forward kernel uses scratch: {fwd}"
+
+
+def test_split_operand_arithmetic_of_bf16x6_and_fp16x3_in_numpy():
+    """The arithmetic behind precision="bf16x6" / "fp16x3" (csrc/split3.hip), restated in numpy with exact (fp64) products and sums:
+    (i) hi + mid + lo of three bf16 roundings IS the fp32 value; (ii) the six largest partial products miss a b by less than 2^-23 |a b|;
+    (iii) two fp16 parts of the value scaled into [2^14, 2^15) hold it to 2^-22 (relative, for entries within 2^-17 of the tensor's
+    largest magnitude) and the three largest products miss a b by less than 2^-20 |a| |b|; (iv) the scale exponent the device derives from a
+    magnitude's bit pattern (141 - biased exponent) puts that magnitude into [2^14, 2^15)."""
+    rng = np.random.default_rng(5)
+
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return u.astype(np.uint32).view(np.float32)
+
+    a = (rng.standard_normal(4096) * np.exp(rng.standard_normal(4096) * 3)).astype(np.float32)
+    b = (rng.standard_normal(4096) * 0.05).astype(np.float32)
+    ah = bf16(a); am = bf16(a - ah); al = bf16(a - ah - am)
+    bh = bf16(b); bm = bf16(b - bh); bl = bf16(b - bh - bm)
+    assert np.array_equal(ah.astype(np.float64) + am + al, a.astype(np.float64))                      # (i)
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    six = sum(x.astype(np.float64) * y for x, y in ((am, bm), (ah, bl), (al, bh), (ah, bm), (am, bh), (ah, bh)))
+    assert np.all(np.abs(six - exact) <= 2.0 ** -23 * np.abs(exact))                                   # (ii)
+    for t in (a, b):                                                                                   # (iv)
+        bits = int(np.abs(t).max().view(np.uint32))
+        k = 141 - (bits >> 23)
+        assert 2.0 ** 14 <= float(np.abs(t).max()) * 2.0 ** k < 2.0 ** 15
+    sa = 2.0 ** (141 - (int(np.abs(a).max().view(np.uint32)) >> 23)); sb = 2.0 ** (141 - (int(np.abs(b).max().view(np.uint32)) >> 23))
+    A, B = (a * np.float32(sa)).astype(np.float32), (b * np.float32(sb)).astype(np.float32)
+    Ah = A.astype(np.float16).astype(np.float32); Am = (A - Ah).astype(np.float16).astype(np.float32)
+    Bh = B.astype(np.float16).astype(np.float32); Bm = (B - Bh).astype(np.float16).astype(np.float32)
+    big = np.abs(A) >= 2.0 ** -3                                                                       # mid is a normal fp16 number there
+    assert np.all(np.abs((Ah.astype(np.float64) + Am) - A)[big] <= 2.0 ** -22 * np.abs(A)[big])
+    three = (Ah.astype(np.float64) * Bm + Am.astype(np.float64) * Bh + Ah.astype(np.float64) * Bh) / (sa * sb)
+    assert np.all(np.abs(three - exact) <= 2.0 ** -20 * np.abs(a.astype(np.float64)) * np.abs(b.astype(np.float64)) + 2.0 ** -24 / (sa * sb) * 2.0 ** 15)   # (iii)
