@@ -301,14 +301,20 @@ def test_16bit_step_of_32_frames_forward_and_backward_vs_oracle(h, precision):
     _run_case(precision, h, 32, 1)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+# max-abs logit error / max(1, max|logit|) over 25 steps: the 16-bit modes' bound, and the fp32 engine's 2e-5 for the split-operand modes
+TRACK_TOL = {"bf16": TOL16["bf16"][0], "fp16": TOL16["fp16"][0], "bf16x6": 2e-5, "fp16x3": 2e-5}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "bf16x6", "fp16x3"])
 def test_16bit_logits_track_the_oracle_over_25_adam_steps_at_224(precision):
     """25 fused bf16 train steps on 32 frames of 224 x 224 (n > 16: the bf16 linear5 / p3 branches), probing the forward on
     the current weights against the fp32 CPU oracle ON THOSE SAME WEIGHTS after 0 and 25 steps. Adam moves every one of
     linear5's 2.5 M input weights per output by ~lr per step, so on the frames being trained the pre-sigmoid logit grows to
     O(10^2 - 10^3) within a few steps (measured: 530 after 5 steps, 2 500 after 25 — the reference never ran at 224 x 224);
     an absolute 1e-3 is then below bf16's resolution of the logit itself. Criterion: max-abs error <= 1e-3 while |logit| <= 1
-    (the north star's regime, random-init weights) and <= 1e-3 of max|logit| beyond."""
+    (the north star's regime, random-init weights) and <= 1e-3 of max|logit| beyond. The split-operand modes ("bf16x6", "fp16x3": their
+    convolutions run on split operands at this size, linear5 on the fp32 kernels) are held to the fp32 engine's 2e-5 instead: 25 steps of
+    their own gradients must not drift from what the fp32 oracle computes on the same weights."""
     n, h = 32, 224
     model = _fresh_model(h, precision, seed=11)
     vis = torch.from_numpy(synth.make_visual(n, h, h))
@@ -340,6 +346,8 @@ def test_16bit_logits_track_the_oracle_over_25_adam_steps_at_224(precision):
         worst.append(d.max().item() / scale)
         del sd, p, b, inter
         gc.collect()
-    assert max(worst) <= TOL16[precision][0], worst
+    assert max(worst) <= TRACK_TOL[precision], worst
+    if precision in ("bf16x6", "fp16x3"):
+        assert any(k[0] == "x2s" for k in model._padbufs), "the split-operand convolutions did not run at this size"
     if precision == "fp16":
         assert model._guard.tolist() == [0, 0], "the automatic loss scale overflowed during ordinary training"
