@@ -963,7 +963,7 @@ class AVM(nn.Module):
         elif "x3s" in ctx:
             dz5s, adz = self._split_mat(dz5, n, 512)
             osc_w = self._osc(adz, ctx["x3s_amax"])
-            fork.run(lambda: ops.linear_bwd_dw_split(self._parts, dz5s, ctx["x3s"], G("visbl.linear5.weight"), n, k5, 512, oscale=osc_w), dz5s)
+            fork.run(lambda: ops.linear_bwd_dw_split(self._parts, dz5s, ctx["x3s"], G("visbl.linear5.weight"), n, k5, 512, oscale=osc_w), dz5s, osc_w)      # osc_w too: the side stream reads it (kept alive until the join)
             bucket_done(1)
             ops.linear_bwd_dx_split(self._parts, dz5s, ctx["w5s"], dbn3.view(n, k5), n, k5, 512, oscale=self._osc(adz, ctx["w5s_amax"]))
             if after_linear5:
@@ -992,7 +992,7 @@ class AVM(nn.Module):
             dys3, ady = self._split_act("dy3s", dy3, None, None, n, hp2, wp2, 512)
             osc_w = self._osc(ady, ctx["x2s_amax"])
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_split, self._parts,
-                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512, osc_w), dys3)
+                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512, osc_w), dys3, osc_w)
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
                                          ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
@@ -1035,7 +1035,7 @@ class AVM(nn.Module):
             dys2, ady2 = self._split_act("dy2s", dy2, None, None, n, hp1, wp1, 256)
             osc_w2 = self._osc(ady2, ctx["x1s_amax"])
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_split, self._parts,
-                                         ctx["x1s"], dys2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256, osc_w2), dys2)
+                                         ctx["x1s"], dys2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256, osc_w2), dys2, osc_w2)
         else:
             fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
                                          ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
