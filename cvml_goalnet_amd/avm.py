@@ -212,11 +212,16 @@ class AVM(nn.Module):
         self._fused_loss, self._fused_loss_done = None, False      # train_step -> forward_device: (labels, loss, dout) for the fused MLP launch
         self._fork = _Fork(self, False)
         self.overlap_rows = int(os.environ.get("GOALNET_OVERLAP_ROWS", "64"))   # steps of <= this many frames fork their off-path work
-        # GOALNET_OVERLAP_LARGE=1: fork at every size AND run the fused Adam over linear5.weight on the side stream as soon as its
-        # gradient exists (train_step's "early Adam") — HBM-bound passes under the MFMA-bound convolution gradients. Built,
-        # bit-identical, and measured WITHOUT gain (1 024 frames @224: fp32 449 -> 453 ms, bf16 78.7 -> 78.6 ms; 10 frames @40:
-        # 845 -> 974 us, the 0.66 GB Adam stream slows every small kernel it runs beside): off by default
-        self.overlap_large = os.environ.get("GOALNET_OVERLAP_LARGE", "0") == "1"
+        # Forking at LARGE sizes: off-path work (weight gradients, bias sums, AudBl) on the side stream AND the fused Adam over linear5.weight
+        # there as soon as its gradient exists (train_step's "early Adam") — HBM-bound passes under MFMA-bound GEMMs and the other way
+        # round. Bit-identical. Measured at 1 024 frames @224 (round 3, alternating runs on one box): bf16 73.7 -> 72.2 ms, fp16x3 182.7 ->
+        # 178.6 ms, bf16x6 297.2 -> 295.6 ms, fp32 417.6 -> 428.7 ms (its GEMMs are 90 % of the step and gain nothing from company); at
+        # 10 frames @40 845 -> 974 us (the 0.66 GB Adam stream slows every small kernel it runs beside). Hence the automatic rule: on for
+        # the 16-bit and split-operand precisions at >= 256 frames, off otherwise. GOALNET_OVERLAP_LARGE=1 forces it at every size and
+        # precision, =0 switches it off.
+        _ol = os.environ.get("GOALNET_OVERLAP_LARGE")
+        self.overlap_large = _ol == "1"
+        self.overlap_auto = _ol is None
         self.time_labels = None        # bench: with kernel_events set, time only these labels (None = all, and no forking)
         self.kernel_events = None      # bench: {label: [(start_event, end_event, flops), ...]} when not None
 
@@ -549,7 +554,11 @@ class AVM(nn.Module):
         kernel's bracket would measure its neighbours too)."""
         if self.kernel_events is not None and self.time_labels is None:
             return False
-        return n <= self.overlap_rows or self.overlap_large
+        return n <= self.overlap_rows or self._large_overlap(n)
+
+    def _large_overlap(self, n):
+        """fork (and run linear5's Adam early) at this size although it is above overlap_rows? (comment at overlap_large)"""
+        return self.overlap_large or (self.overlap_auto and self._precision != "fp32" and n >= 256)
 
     @staticmethod
     def _bwd16_ok(wc):
@@ -1149,7 +1158,7 @@ class AVM(nn.Module):
         # One GPU, no gradient exchange, no overflow guard to consult: linear5.weight (99.8 % of the parameters at 224 x 224) gets
         # its Adam pass the moment its gradient exists and its last reader of the step (the data gradient) is enqueued — on the
         # side stream, i.e. 36 GB of HBM traffic under the MFMA-bound convolution gradients that follow instead of after them
-        early = sync is None and self.precision != "fp16" and self.overlap_large and self._fork_ok(n)
+        early = sync is None and self.precision != "fp16" and self._large_overlap(n) and self._fork_ok(n)
         # Small steps (the reference's 10-frame sub-batches): the same idea as a BACKGROUND pass — the update of linear5.weight (90 % of
         # the step's 0.66 GB of optimizer traffic) on a third stream and on a bounded number of blocks. Built, bit-identical, and
         # measured WITHOUT gain at any width (GOALNET_EARLY_ADAM_BLOCKS=64 / 128 / 256 / 512: 1 226 / 1 042 / 990 / 980 us per step

@@ -164,7 +164,7 @@ def test_side_stream_overlap_changes_nothing_but_the_schedule(precision, large):
     h, sb = 40, 10
     aud, vis, lab = _video(47, h, True, 21)
     ref, forked = load_model(h, True, precision), load_model(h, True, precision)
-    ref.overlap_rows, ref.overlap_large = 0, False                        # everything on the current stream, Adam after backward
+    ref.overlap_rows, ref.overlap_large, ref.overlap_auto = 0, False, False      # everything on the current stream, Adam after backward
     forked.overlap_large = large                                          # True: also the early Adam on linear5.weight (off by default)
     e_loss, e_pred = [], []
     for a in range(0, 47, sb):
