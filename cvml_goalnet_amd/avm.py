@@ -884,6 +884,14 @@ class AVM(nn.Module):
         # small steps: weight / bias gradients and the AudBl branch run on a side stream under the dX chain (_Fork)
         fork = self._fork = _Fork(self, self._fork_ok(n) and dout.is_cuda)
         self._dbias_pending = {}
+        # Large steps (forked by _large_overlap): the side stream's pieces are paired with main-stream work of the OTHER kind — linear5's
+        # Adam (HBM-bound) goes out when conv3's data gradient (MFMA-bound) starts, each weight gradient (MFMA-bound) when its layer's
+        # data gradient is enqueued, i.e. under the BatchNorm / pool passes of the next block (HBM-bound). Small steps keep the weight
+        # gradient FIRST: there the chain is latency-bound and everything off it should start as early as it can. Same kernels, same
+        # results either way. Measured (1 024 frames, alternating runs): fp16x3 178.5 -> 176.9 ms, bf16 70.6 -> 70.6 (GOALNET_OVERLAP_PAIR=0
+        # restores the weight-gradient-first order).
+        pair = fork.enabled and self._large_overlap(n) and os.environ.get("GOALNET_OVERLAP_PAIR", "1") != "0"
+        deferred_l5 = []
 
         def bucket_done(k):
             if on_bucket:
@@ -968,7 +976,7 @@ class AVM(nn.Module):
             else:
                 ops.linear_bwd_dx_bf16(dz5b, ctx["w5b"], dbn3.view(n, k5), mult=None)
             if after_linear5:
-                after_linear5(fork)
+                deferred_l5.append(after_linear5) if pair else after_linear5(fork)
         elif "x3s" in ctx:
             dz5s, adz = self._split_mat(dz5, n, 512)
             osc_w = self._osc(adz, ctx["x3s_amax"])
@@ -976,23 +984,25 @@ class AVM(nn.Module):
             bucket_done(1)
             ops.linear_bwd_dx_split(self._parts, dz5s, ctx["w5s"], dbn3.view(n, k5), n, k5, 512, oscale=self._osc(adz, ctx["w5s_amax"]))
             if after_linear5:
-                after_linear5(fork)
+                deferred_l5.append(after_linear5) if pair else after_linear5(fork)
         else:
             fork.run(lambda: ops.linear_bwd_dw(dz5, p3f, G("visbl.linear5.weight"), scale=st3[2], shift=st3[3], bnC=512), dz)
             bucket_done(1)
             ops.linear_bwd_dx(dz5, P("visbl.linear5.weight"), dbn3.view(n, k5), mult=None)
             if after_linear5:
-                after_linear5(fork)
+                deferred_l5.append(after_linear5) if pair else after_linear5(fork)
 
         # block 3 (utils.py:184-187)
         dy3 = self._block_bwd(dbn3, ctx, 3, n, hp2, wp2, 512)
         del dbn3
+        for cb in deferred_l5:                       # pair: linear5's Adam starts here, beside conv3's data gradient
+            cb(fork)
         st2 = ctx["st2"]
         x6_3 = "x2s" in ctx                          # precision="bf16x6" and the forward ran conv3 on split operands
         if bf:
             dyp3 = dy3
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
-                                         ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
+            wg3 = lambda dyp3=dyp3: fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_bf16,
+                                                                 ctx["xh2"], dyp3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dyp3)
         elif x6_3:
             if ctx["x2s_gen"] != self._padgen["x2s"]:
                 raise RuntimeError("precision='bf16x6': a second training-mode forward overwrote the saved split operands before "
@@ -1000,11 +1010,14 @@ class AVM(nn.Module):
             # the weight gradient and the data gradient read the gradient as 16-bit parts in the padded layout: one split pass
             dys3, ady = self._split_act("dy3s", dy3, None, None, n, hp2, wp2, 512)
             osc_w = self._osc(ady, ctx["x2s_amax"])
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_split, self._parts,
-                                         ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512, osc_w), dys3, osc_w)
+            wg3 = lambda dys3=dys3, osc_w=osc_w: fork.run(
+                lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad_split, self._parts,
+                                    ctx["x2s"], dys3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512, osc_w), dys3, osc_w)
         else:
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
-                                         ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
+            wg3 = lambda dy3=dy3: fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp2 * wp2 * 2304 * 512, ops.conv3x3_wgrad,
+                                                               ctx["p2"], st2[2], st2[3], dy3, G("visbl.conv3.weight"), n, hp2, wp2, 256, 512), dy3)
+        if not pair:
+            wg3()
         wt = wt3
         if flips_early:
             fork.wait(flips_ev)
@@ -1028,6 +1041,8 @@ class AVM(nn.Module):
         else:
             self._timed("conv_dgrad", 2.0 * n * hp2 * wp2 * 4608 * 256, ops.conv3x3_fwd,
                         dy3, None, None, wt, None, False, dbn2, n, hp2, wp2, 512, 256)
+        if pair:
+            wg3()                                    # behind the data gradient: runs under block 2's BatchNorm / pool passes
         del dy3
 
         # block 2 (utils.py:179-182)
@@ -1036,18 +1051,21 @@ class AVM(nn.Module):
         st1 = ctx["st1"]
         if bf:
             dyp2 = dy2
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
-                                         ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
+            wg2 = lambda dyp2=dyp2: fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_bf16,
+                                                                 ctx["xh1"], dyp2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dyp2)
         elif "x1s" in ctx:
             if ctx["x1s_gen"] != self._padgen["x1s"]:
                 raise RuntimeError("precision='fp16x3': a second training-mode forward overwrote the saved split operands before backward ran")
             dys2, ady2 = self._split_act("dy2s", dy2, None, None, n, hp1, wp1, 256)
             osc_w2 = self._osc(ady2, ctx["x1s_amax"])
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_split, self._parts,
-                                         ctx["x1s"], dys2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256, osc_w2), dys2, osc_w2)
+            wg2 = lambda dys2=dys2, osc_w2=osc_w2: fork.run(
+                lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad_split, self._parts,
+                                    ctx["x1s"], dys2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256, osc_w2), dys2, osc_w2)
         else:
-            fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
-                                         ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
+            wg2 = lambda dy2=dy2: fork.run(lambda: self._timed("conv_wgrad", 2.0 * n * hp1 * wp1 * 576 * 256, ops.conv3x3_wgrad,
+                                                               ctx["p1"], st1[2], st1[3], dy2, G("visbl.conv2.weight"), n, hp1, wp1, 64, 256), dy2)
+        if not pair:
+            wg2()
         wt = wt2
         if not flips_early:
             ops.conv3x3_weight_flip(P("visbl.conv2.weight"), wt, 256, 64)
@@ -1065,6 +1083,8 @@ class AVM(nn.Module):
         else:
             self._timed("conv_dgrad", 2.0 * n * hp1 * wp1 * 2304 * 64, ops.conv3x3_fwd,
                         dy2, None, None, wt, None, False, dbn1, n, hp1, wp1, 256, 64)
+        if pair:
+            wg2()
         del dy2
 
         # block 1 (utils.py:174-177); conv1's input needs no gradient
