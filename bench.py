@@ -333,7 +333,7 @@ def x6_roofline(roof, others, nseg=6.0):
     roof["achieved"] = nseg * roof["useful_tflops"]
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["mfma_flops_per_launch"] = nseg * roof["algorithmic_flops_per_launch"]
-    roof["kernel"] = roof["kernel"].replace("256<64, 0>", "256<64, %d>" % nseg).replace("256<32, 0>", "256<32, %d>" % nseg) \
+    roof["kernel"] = roof["kernel"].replace("ConvAPadLoader256<64>", "ConvAPadLoader256<64, %d>" % nseg).replace("KCLoader256<32>", "KCLoader256<32, %d>" % nseg) \
         .replace(", 0, false>", ", 0, true>" if nseg == 3.0 else ", 0, false>") \
         + "; split operands %s, %d K-segments per launch (csrc/split3.hip)" % ("[hi | mid | lo] (bf16)" if nseg == 6.0 else "[hi | mid] (scaled fp16)", nseg)
     roof["traffic"], roof["traffic_source"] = None, "no counter pass for the split-operand launches"
