@@ -406,7 +406,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     // while the previous tile's epilogue runs (one register), the tile start puts it into LDS (1 KB beside the 128 KB of
     // operands) and the accumulators are initialised from there. Otherwise all 16 registers of acc[.][j] are column
     // 32 j + (lane & 31): two registers.
-    __shared__ __attribute__((aligned(16))) float bias_lds[T];
+    // two copies, used alternately by consecutive tiles: a wave that is already at the top of the next tile writes the OTHER copy while a
+    // slower wave may still be reading this tile's in its epilogue (LATE_BIAS); waves are never more than one tile apart (the phases'
+    // barriers keep them together inside a tile)
+    __shared__ __attribute__((aligned(16))) float bias_lds[2][T];
+    int bias_par = 0;
     float bias_t = 0.f, bias_col[2] = {0.f, 0.f};
 #define GN_LOAD_BIAS()                                                                                      \
     if constexpr (ROLE == 0) {                                                                              \
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
   for (;;) {
     GN_STAMP(0)
     if constexpr (SWAP && ROLE == 0) {
-        if (tid < T) bias_lds[tid] = bias_t;
+        if (tid < T) bias_lds[bias_par][tid] = bias_t;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     GN_STAMP(1)
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (ROLE == 0 && !LATE_BIAS) b4 = *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5)]);
+                if constexpr (ROLE == 0 && !LATE_BIAS) b4 = *reinterpret_cast<const float4*>(&bias_lds[bias_par][wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5)]);
                 bj[4 * g] = b4.x; bj[4 * g + 1] = b4.y; bj[4 * g + 2] = b4.z; bj[4 * g + 3] = b4.w;
             }
 #pragma unroll
@@ -567,10 +571,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
         if constexpr (ROLE == 0) return ep.relu ? fmaxf(v, 0.f) : v;
         else return v;
     };
-    // LATE_BIAS: the four bias values of register group g of acc[.][ni] (this tile's columns are still in bias_lds: the next tile's are
-    // written at the top of the loop, behind a barrier every wave joins after its epilogue)
+    // LATE_BIAS: the four bias values of register group g of acc[.][ni] (this tile's copy of bias_lds; the next tile writes the other one)
     auto bias4 = [&](int ni, int g) -> float4 {
-        if constexpr (LATE_BIAS) return *reinterpret_cast<const float4*>(&bias_lds[wc * 64 + ni * 32 + 8 * g + 4 * (lane >> 5)]);
+        if constexpr (LATE_BIAS) return *reinterpret_cast<const float4*>(&bias_lds[bias_par][wc * 64 + ni * 32 + 8 * g + 4 * (lane >> 5)]);
         else return make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float* outp = ep.out + (ep.slab_stride > 0 ? (int64_t)split * ep.slab_stride : 0);
@@ -710,6 +713,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(typename AL::P ap
     } while (0);
     if (!more) break;
     vb = vb_next;
+    bias_par ^= 1;
   }
 #undef GN_PROLOGUE
 #undef GN_WAIT_KTILE0

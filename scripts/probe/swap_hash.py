@@ -15,7 +15,8 @@ from cvml_goalnet_amd import ops  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.manual_seed(1)
 for h16 in (torch.bfloat16, torch.float16):
-    for (n, hh, ww, cin, cout) in ((16, 56, 56, 256, 512), (3, 37, 29, 256, 512), (16, 112, 112, 64, 256), (5, 56, 56, 512, 256)):
+    # the last shape has THREE column tiles and > 256 tiles: a walking block meets a different tile column (another bias slice) every step
+    for (n, hh, ww, cin, cout) in ((16, 56, 56, 256, 512), (3, 37, 29, 256, 512), (16, 112, 112, 64, 256), (5, 56, 56, 512, 256), (8, 72, 72, 64, 768)):
         x = torch.randn(n, hh, ww, cin, device=dev)
         sc = torch.ones(cin, device=dev)
         sh = torch.zeros(cin, device=dev)
@@ -74,3 +75,24 @@ for h16 in (torch.bfloat16, torch.float16):
         ops.linear_bwd_dw_bf16(dy, x, dw)
         out.append(dw)
         print(str(h16)[6:], "linear", M, K, J, *h(*out), float(dw.abs().max()), float(dx.abs().max()))
+
+
+# split operands (parts = 3: bf16 triples; parts = 2: scaled fp16 pairs, bias added after the unscaling from the per-tile LDS copy): three
+# column tiles, > 256 tiles, bias + ReLU
+for parts in (3, 2):
+    dt = torch.bfloat16 if parts == 3 else torch.float16
+    n, hh, ww, cin, cout = 8, 72, 72, 64, 768
+    x = torch.randn(n, hh, ww, cin, device=dev)
+    w = torch.randn(cout * 9 * cin, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    ax = aw = osc = None
+    if parts == 2:
+        ax = ops.absmax(x, torch.zeros(1, dtype=torch.int32, device=dev), n * hh * ww, cin)
+        aw = ops.absmax(w, torch.zeros(1, dtype=torch.int32, device=dev), cout * 9, cin)
+        osc = ops.split_scales(ax, aw)
+    _, xp = ops.padded_bf16_alloc(n, hh, ww, parts * cin, dev, dtype=dt)
+    ops.split_padded(parts, x, None, None, xp, n, hh, ww, cin, amax=ax)
+    wsp = ops.split_rows(parts, w, torch.empty(cout * 9 * parts * cin, dtype=dt, device=dev), cout * 9, cin, amax=aw)
+    y = torch.full((n, hh, ww, cout), 7.0, device=dev)
+    ops.conv3x3_fwd_split(parts, xp, wsp, b, True, y, n, hh, ww, cin, cout, oscale=osc)
+    print("split", parts, n, hh, ww, cin, cout, *h(y), float(y.abs().max()))
